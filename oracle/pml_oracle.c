@@ -1,0 +1,799 @@
+/*
+ * pml_oracle.c -- CPU oracle (TEST INFRASTRUCTURE ONLY; see pml_oracle.h header).
+ *
+ * PARITY UNPINNED vs the reference's bundled FastTree_WAG / raxmlHPC executables (they may not
+ * be executed here and the reference holds no golden vectors); pinned by independent checks
+ * listed in pml_oracle.h.  Reference call sites this restates the arithmetic behind:
+ *   RAxMLRunner.java:115-147 (-f d / -f e / -f g, -m PROTGAMMAWAG), FastTreeRunner.java:67-94.
+ */
+#include "pml_oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
+
+#define PO_TMIN 1.0e-6     /* RAxML 7.2.5: zmax = 1-1e-6  -> t >= ~1e-6 */
+#define PO_TMAX 34.5       /* RAxML 7.2.5: zmin = 1e-15   -> t <= 34.5 */
+#define PO_ALPHA_MIN 0.02
+#define PO_ALPHA_MAX 1000.0
+#define PO_SCALE_THRESH 1.1579208923731620e-77  /* 2^-256 (RAxML "minlikelihood") */
+#define PO_SCALE_MULT   8.6361685550944446e+76  /* 2^255? no: set at init to 2^256 */
+#define PO_LOG_2_256    177.44567822334599      /* 256 ln 2 */
+
+/* ------------------------------------------------------------------------------------------
+ * WAG constants (Whelan & Goldman 2001, PAML wag.dat lower triangle; order ARNDCQEGHILKMFPSTWYV)
+ * ---------------------------------------------------------------------------------------- */
+static const double WAG_LOWER[190] = {
+0.551571,
+0.509848, 0.635346,
+0.738998, 0.147304, 5.429420,
+1.027040, 0.528191, 0.265256, 0.0302949,
+0.908598, 3.035500, 1.543640, 0.616783, 0.0988179,
+1.582850, 0.439157, 0.947198, 6.174160, 0.021352, 5.469470,
+1.416720, 0.584665, 1.125560, 0.865584, 0.306674, 0.330052, 0.567717,
+0.316954, 2.137150, 3.956290, 0.930676, 0.248972, 4.294110, 0.570025, 0.249410,
+0.193335, 0.186979, 0.554236, 0.039437, 0.170135, 0.113917, 0.127395, 0.0304501, 0.138190,
+0.397915, 0.497671, 0.131528, 0.0848047, 0.384287, 0.869489, 0.154263, 0.0613037, 0.499462, 3.170970,
+0.906265, 5.351420, 3.012010, 0.479855, 0.0740339, 3.894900, 2.584430, 0.373558, 0.890432, 0.323832, 0.257555,
+0.893496, 0.683162, 0.198221, 0.103754, 0.390482, 1.545260, 0.315124, 0.174100, 0.404141, 4.257460, 4.854020, 0.934276,
+0.210494, 0.102711, 0.0961621, 0.0467304, 0.398020, 0.0999208, 0.0811339, 0.049931, 0.679371, 1.059470, 2.115170, 0.088836, 1.190630,
+1.438550, 0.679489, 0.195081, 0.423984, 0.109404, 0.933372, 0.682355, 0.243570, 0.696198, 0.0999288, 0.415844, 0.556896, 0.171329, 0.161444,
+3.370790, 1.224190, 3.974230, 1.071760, 1.407660, 1.028870, 0.704939, 1.341820, 0.740169, 0.319440, 0.344739, 0.967130, 0.493905, 0.545931, 1.613280,
+2.121110, 0.554413, 2.030060, 0.374866, 0.512984, 0.857928, 0.822765, 0.225833, 0.473307, 1.458160, 0.326622, 1.386980, 1.516120, 0.171903, 0.795384, 4.378020,
+0.113133, 1.163920, 0.0719167, 0.129767, 0.717070, 0.215737, 0.156557, 0.336983, 0.262569, 0.212483, 0.665309, 0.137505, 0.515706, 1.529640, 0.139405, 0.523742, 0.110864,
+0.240735, 0.381533, 1.086000, 0.325711, 0.543833, 0.227710, 0.196303, 0.103604, 3.873440, 0.420170, 0.398618, 0.133264, 0.428437, 6.454280, 0.216046, 0.786993, 0.291148, 2.485390,
+2.006010, 0.251849, 0.196246, 0.152335, 1.002140, 0.301281, 0.588731, 0.187247, 0.118358, 7.821300, 1.800340, 0.305434, 2.058450, 0.649892, 0.314887, 0.232739, 1.388230, 0.365369, 0.314730
+};
+static const double WAG_PI_FULL[20] = {
+0.0866279, 0.043972, 0.0390894, 0.0570451, 0.0193078, 0.0367281, 0.0580589, 0.0832518, 0.0244313,
+0.048466, 0.086209, 0.0620286, 0.0195027, 0.0384319, 0.0457631, 0.0695179, 0.0610127, 0.0143859,
+0.0352742, 0.0708956 };
+/* RAxML 7.2.5 PROTGAMMAWAG base frequencies (3 decimals, sum 1.000; pi(I)=0.049) */
+static const double WAG_PI_3DP[20] = {
+0.087, 0.044, 0.039, 0.057, 0.019, 0.037, 0.058, 0.083, 0.024, 0.049, 0.086, 0.062, 0.020, 0.038,
+0.046, 0.070, 0.061, 0.014, 0.035, 0.071 };
+
+void po_wag_tables(double S[PO_NS][PO_NS], double pi_full[PO_NS], double pi_3dp[PO_NS]) {
+    int i, j, k = 0;
+    for (i = 0; i < 20; i++) S[i][i] = 0.0;
+    for (i = 1; i < 20; i++)
+        for (j = 0; j < i; j++) { S[i][j] = S[j][i] = WAG_LOWER[k++]; }
+    for (i = 0; i < 20; i++) { pi_full[i] = WAG_PI_FULL[i]; pi_3dp[i] = WAG_PI_3DP[i]; }
+}
+
+/* cyclic Jacobi eigen-decomposition of a symmetric 20x20 matrix: A = V diag(d) V^T */
+static void jacobi20(double A[PO_NS][PO_NS], double d[PO_NS], double V[PO_NS][PO_NS]) {
+    int n = PO_NS, i, j, p, q, sweep;
+    for (i = 0; i < n; i++) for (j = 0; j < n; j++) V[i][j] = (i == j);
+    for (sweep = 0; sweep < 100; sweep++) {
+        double off = 0.0;
+        for (p = 0; p < n; p++) for (q = p + 1; q < n; q++) off += A[p][q] * A[p][q];
+        if (off < 1e-40) break;
+        for (p = 0; p < n; p++)
+            for (q = p + 1; q < n; q++) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (i = 0; i < n; i++) {
+                    double aip = A[i][p], aiq = A[i][q];
+                    A[i][p] = c * aip - s * aiq; A[i][q] = s * aip + c * aiq;
+                }
+                for (i = 0; i < n; i++) {
+                    double api = A[p][i], aqi = A[q][i];
+                    A[p][i] = c * api - s * aqi; A[q][i] = s * api + c * aqi;
+                }
+                for (i = 0; i < n; i++) {
+                    double vip = V[i][p], viq = V[i][q];
+                    V[i][p] = c * vip - s * viq; V[i][q] = s * vip + c * viq;
+                }
+            }
+    }
+    for (i = 0; i < n; i++) d[i] = A[i][i];
+    /* sort descending (eigenvalue 0 first) for determinism */
+    for (i = 0; i < n; i++) {
+        int best = i;
+        for (j = i + 1; j < n; j++) if (d[j] > d[best]) best = j;
+        if (best != i) {
+            double tmp = d[i]; d[i] = d[best]; d[best] = tmp;
+            for (j = 0; j < n; j++) { tmp = V[j][i]; V[j][i] = V[j][best]; V[j][best] = tmp; }
+        }
+    }
+}
+
+void po_model_init(po_model *m, int pi_mode) {
+    double S[PO_NS][PO_NS], pf[PO_NS], p3[PO_NS], B[PO_NS][PO_NS], V[PO_NS][PO_NS];
+    int i, j;
+    po_wag_tables(S, pf, p3);
+    double sum = 0;
+    for (i = 0; i < 20; i++) { m->pi[i] = (pi_mode == PO_PI_FULL) ? pf[i] : p3[i]; sum += m->pi[i]; }
+    for (i = 0; i < 20; i++) m->pi[i] /= sum;
+    double mu = 0;
+    for (i = 0; i < 20; i++) {
+        double row = 0;
+        for (j = 0; j < 20; j++) if (j != i) { m->Q[i][j] = S[i][j] * m->pi[j]; row += m->Q[i][j]; }
+        m->Q[i][i] = -row; mu += m->pi[i] * row;
+    }
+    for (i = 0; i < 20; i++) for (j = 0; j < 20; j++) m->Q[i][j] /= mu;
+    for (i = 0; i < 20; i++) for (j = 0; j < 20; j++)
+        B[i][j] = sqrt(m->pi[i]) * m->Q[i][j] / sqrt(m->pi[j]);
+    for (i = 0; i < 20; i++) for (j = i + 1; j < 20; j++) { B[i][j] = B[j][i] = 0.5 * (B[i][j] + B[j][i]); }
+    jacobi20(B, m->eval, V);
+    for (i = 0; i < 20; i++) for (j = 0; j < 20; j++) {
+        m->U[i][j] = V[i][j] / sqrt(m->pi[i]);
+        m->Uinv[j][i] = V[i][j] * sqrt(m->pi[i]);
+    }
+}
+
+void po_pmatrix(const po_model *m, double t, double P[PO_NS][PO_NS]) {
+    double e[PO_NS]; int i, j, k;
+    for (k = 0; k < 20; k++) e[k] = exp(m->eval[k] * t);
+    for (i = 0; i < 20; i++) for (j = 0; j < 20; j++) {
+        double s = 0;
+        for (k = 0; k < 20; k++) s += m->U[i][k] * e[k] * m->Uinv[k][j];
+        P[i][j] = s < 0 ? 0.0 : s;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * discrete Gamma (Yang 1994)
+ * ---------------------------------------------------------------------------------------- */
+double po_lngamma(double x) { return lgamma(x); }
+
+double po_incgamma(double a, double x) {
+    if (x <= 0) return 0.0;
+    double gln = lgamma(a);
+    if (x < a + 1.0) {                      /* series */
+        double ap = a, sum = 1.0 / a, del = sum; int n;
+        for (n = 0; n < 100000; n++) { ap += 1.0; del *= x / ap; sum += del; if (fabs(del) < fabs(sum) * 1e-17) break; }
+        return sum * exp(-x + a * log(x) - gln);
+    } else {                                /* continued fraction (modified Lentz) */
+        double tiny = 1e-300, b = x + 1.0 - a, c = 1.0 / tiny, d = 1.0 / b, h = d; int i;
+        for (i = 1; i < 100000; i++) {
+            double an = -i * (i - a); b += 2.0;
+            d = an * d + b; if (fabs(d) < tiny) d = tiny;
+            c = b + an / c; if (fabs(c) < tiny) c = tiny;
+            d = 1.0 / d; double del = d * c; h *= del;
+            if (fabs(del - 1.0) < 1e-16) break;
+        }
+        return 1.0 - exp(-x + a * log(x) - gln) * h;
+    }
+}
+
+double po_gamma_quantile(double p, double a) {
+    /* bisection on log x: robust for alpha down to 0.02 */
+    double lo = -1600.0, hi = log(a + 40.0 * sqrt(a) + 400.0); int i;
+    for (i = 0; i < 400; i++) {
+        double mid = 0.5 * (lo + hi);
+        if (po_incgamma(a, exp(mid)) < p) lo = mid; else hi = mid;
+        if (hi - lo < 1e-15 * fmax(1.0, fabs(mid))) break;
+    }
+    return exp(0.5 * (lo + hi));
+}
+
+void po_gamma_rates(double alpha, int K, int median, double *rates) {
+    int i;
+    if (K == 1) { rates[0] = 1.0; return; }
+    if (median) {
+        double s = 0;
+        for (i = 0; i < K; i++) { rates[i] = po_gamma_quantile((2.0 * i + 1.0) / (2.0 * K), alpha) / alpha; s += rates[i]; }
+        for (i = 0; i < K; i++) rates[i] *= K / s;
+        return;
+    }
+    double prev = 0.0;
+    for (i = 0; i < K; i++) {
+        double cur = (i == K - 1) ? 1.0 : po_incgamma(alpha + 1.0, po_gamma_quantile((i + 1.0) / K, alpha));
+        rates[i] = (cur - prev) * K; prev = cur;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * alignment
+ * ---------------------------------------------------------------------------------------- */
+int po_char_code(int c) {
+    static const char *aa = "ARNDCQEGHILKMFPSTWYV";
+    c = toupper(c);
+    const char *p = (c != 0) ? strchr(aa, c) : NULL;
+    if (p) return (int)(p - aa);
+    if (c == 'B') return 20;
+    if (c == 'Z') return 21;
+    return 22;
+}
+unsigned po_code_mask(int code) {
+    if (code < 20) return 1u << code;
+    if (code == 20) return (1u << 2) | (1u << 3);   /* B = N or D */
+    if (code == 21) return (1u << 5) | (1u << 6);   /* Z = Q or E */
+    return 0xFFFFFu;
+}
+
+po_aln *po_aln_create(int ntax, int nsites, const char *const *names, const char *const *rows, int compress) {
+    po_aln *a = (po_aln *)calloc(1, sizeof(po_aln));
+    int i, s;
+    a->ntax = ntax; a->nsites = nsites;
+    a->names = (char **)calloc(ntax, sizeof(char *));
+    for (i = 0; i < ntax; i++) a->names[i] = strdup(names[i]);
+    unsigned char *col = (unsigned char *)malloc((size_t)ntax * nsites);   /* [site][tax] */
+    for (i = 0; i < ntax; i++) for (s = 0; s < nsites; s++) col[(size_t)s * ntax + i] = (unsigned char)po_char_code(rows[i][s]);
+    a->site2pat = (int *)malloc(sizeof(int) * (nsites > 0 ? nsites : 1));
+    int *first = (int *)malloc(sizeof(int) * (nsites > 0 ? nsites : 1));   /* pattern -> first site */
+    a->weight = (int *)calloc(nsites > 0 ? nsites : 1, sizeof(int));
+    int hsize = 1; while (hsize < 2 * nsites + 16) hsize <<= 1;
+    int *table = (int *)malloc(sizeof(int) * hsize);
+    for (i = 0; i < hsize; i++) table[i] = -1;
+    int npat = 0;
+    for (s = 0; s < nsites; s++) {
+        const unsigned char *c = col + (size_t)s * ntax;
+        int pat = -1;
+        if (compress) {
+            unsigned long long h = 1469598103934665603ULL;
+            for (i = 0; i < ntax; i++) { h ^= c[i]; h *= 1099511628211ULL; }
+            int slot = (int)(h & (unsigned)(hsize - 1));
+            while (table[slot] >= 0) {
+                if (memcmp(col + (size_t)first[table[slot]] * ntax, c, ntax) == 0) { pat = table[slot]; break; }
+                slot = (slot + 1) & (hsize - 1);
+            }
+            if (pat < 0) { table[slot] = npat; }
+        }
+        if (pat < 0) { pat = npat; first[npat++] = s; }
+        a->site2pat[s] = pat; a->weight[pat]++;
+    }
+    a->npat = npat;
+    a->codes = (unsigned char *)malloc((size_t)ntax * (npat > 0 ? npat : 1));
+    for (i = 0; i < ntax; i++) for (s = 0; s < npat; s++) a->codes[(size_t)i * npat + s] = col[(size_t)first[s] * ntax + i];
+    free(col); free(first); free(table);
+    return a;
+}
+void po_aln_free(po_aln *a) {
+    if (!a) return;
+    for (int i = 0; i < a->ntax; i++) free(a->names[i]);
+    free(a->names); free(a->codes); free(a->weight); free(a->site2pat); free(a);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * tree
+ * ---------------------------------------------------------------------------------------- */
+typedef struct pnode { int parent, nchild, cap; int *child; double len; int haslen; int tip; } pnode;
+typedef struct { const char *s; int pos; pnode *n; int nn, cap; const po_aln *a; char *err; int errlen; int fail; int *seen; } pstate;
+
+static int p_new(pstate *st) {
+    if (st->nn == st->cap) { st->cap = st->cap ? 2 * st->cap : 64; st->n = (pnode *)realloc(st->n, sizeof(pnode) * st->cap); }
+    pnode *x = &st->n[st->nn]; memset(x, 0, sizeof(*x)); x->parent = -1; x->tip = -1; x->len = 0.1;
+    return st->nn++;
+}
+static void p_addchild(pstate *st, int p, int c) {
+    pnode *x = &st->n[p];
+    if (x->nchild == x->cap) { x->cap = x->cap ? 2 * x->cap : 4; x->child = (int *)realloc(x->child, sizeof(int) * x->cap); }
+    x->child[x->nchild++] = c; st->n[c].parent = p;
+}
+static void p_fail(pstate *st, const char *msg) { if (!st->fail && st->err) snprintf(st->err, st->errlen, "%s (at char %d)", msg, st->pos); st->fail = 1; }
+static void p_ws(pstate *st) {
+    for (;;) {
+        while (st->s[st->pos] && isspace((unsigned char)st->s[st->pos])) st->pos++;
+        if (st->s[st->pos] == '[') { while (st->s[st->pos] && st->s[st->pos] != ']') st->pos++; if (st->s[st->pos]) st->pos++; }
+        else break;
+    }
+}
+static int p_subtree(pstate *st);
+static void p_label_len(pstate *st, int id, int isleaf) {
+    p_ws(st);
+    int b = st->pos;
+    if (st->s[st->pos] == '\'') { st->pos++; b = st->pos; while (st->s[st->pos] && st->s[st->pos] != '\'') st->pos++; }
+    else while (st->s[st->pos] && !strchr(",():;[", st->s[st->pos]) && !isspace((unsigned char)st->s[st->pos])) st->pos++;
+    int e = st->pos;
+    if (st->s[st->pos] == '\'') st->pos++;
+    if (isleaf) {
+        int i, found = -1;
+        for (i = 0; i < st->a->ntax; i++) if ((int)strlen(st->a->names[i]) == e - b && strncmp(st->a->names[i], st->s + b, e - b) == 0) { found = i; break; }
+        if (found < 0) { p_fail(st, "leaf name not in alignment"); return; }
+        if (st->seen[found]) { p_fail(st, "duplicate leaf name"); return; }
+        st->seen[found] = 1; st->n[id].tip = found;
+    }
+    p_ws(st);
+    if (st->s[st->pos] == ':') {
+        st->pos++; p_ws(st);
+        char *end; double v = strtod(st->s + st->pos, &end);
+        if (end == st->s + st->pos) { p_fail(st, "bad branch length"); return; }
+        st->pos = (int)(end - st->s); st->n[id].len = v; st->n[id].haslen = 1;
+    }
+    p_ws(st);
+}
+static int p_subtree(pstate *st) {
+    if (st->fail) return -1;
+    p_ws(st);
+    int id = p_new(st);
+    if (st->s[st->pos] == '(') {
+        st->pos++;
+        for (;;) {
+            int c = p_subtree(st); if (st->fail) return -1;
+            p_addchild(st, id, c); p_ws(st);
+            if (st->s[st->pos] == ',') { st->pos++; continue; }
+            if (st->s[st->pos] == ')') { st->pos++; break; }
+            p_fail(st, "expected , or )"); return -1;
+        }
+        p_label_len(st, id, 0);
+    } else p_label_len(st, id, 1);
+    return id;
+}
+
+static void t_connect(po_tree *t, int a, int b, double len) {
+    int k;
+    for (k = 0; k < 3 && t->nbr[a][k] >= 0; k++) ;
+    t->nbr[a][k] = b; t->len[a][k] = len;
+    for (k = 0; k < 3 && t->nbr[b][k] >= 0; k++) ;
+    t->nbr[b][k] = a; t->len[b][k] = len;
+}
+static po_tree *t_alloc(int ntax) {
+    po_tree *t = (po_tree *)calloc(1, sizeof(po_tree));
+    t->ntax = ntax; t->nnodes = 2 * ntax - 2;
+    t->nbr = (int (*)[3])malloc(sizeof(int[3]) * t->nnodes);
+    t->len = (double (*)[3])calloc(t->nnodes, sizeof(double[3]));
+    for (int i = 0; i < t->nnodes; i++) t->nbr[i][0] = t->nbr[i][1] = t->nbr[i][2] = -1;
+    return t;
+}
+
+/* convert parsed rooted multifurcating structure (node r, attached to parent id `up` with length
+ * `len`) into the binary unrooted array form; polytomies resolved with PO_TMIN branches */
+static int t_build(pstate *st, po_tree *t, int r, int *next_inner) {
+    pnode *x = &st->n[r];
+    while (x->nchild == 1) {                 /* collapse unary nodes */
+        int c = x->child[0]; st->n[c].len += x->len * (x->parent >= 0); r = c; x = &st->n[r];
+    }
+    if (x->nchild == 0) return x->tip;
+    int id = (*next_inner)++;
+    /* resolve to two children */
+    int nc = x->nchild, i;
+    int *ids = (int *)malloc(sizeof(int) * nc); double *ls = (double *)malloc(sizeof(double) * nc);
+    for (i = 0; i < nc; i++) {
+        int c = x->child[i]; double l = st->n[c].len; int cc = c;
+        while (st->n[cc].nchild == 1) { cc = st->n[cc].child[0]; l += st->n[cc].len; }
+        ls[i] = l; ids[i] = t_build(st, t, c, next_inner);
+        x = &st->n[r];
+    }
+    int cur = ids[0]; double curl = ls[0];
+    for (i = 1; i < nc - 1; i++) {           /* ladderise extra children */
+        int nid = (*next_inner)++;
+        t_connect(t, nid, cur, curl); t_connect(t, nid, ids[i], ls[i]);
+        cur = nid; curl = PO_TMIN;
+    }
+    t_connect(t, id, cur, curl); t_connect(t, id, ids[nc - 1], ls[nc - 1]);
+    free(ids); free(ls);
+    return id;
+}
+
+po_tree *po_tree_parse(const char *newick, const po_aln *a, char *err, int errlen) {
+    pstate st; memset(&st, 0, sizeof(st));
+    st.s = newick; st.a = a; st.err = err; st.errlen = errlen;
+    st.seen = (int *)calloc(a->ntax, sizeof(int));
+    if (err && errlen) err[0] = 0;
+    int root = p_subtree(&st);
+    po_tree *t = NULL;
+    int i;
+    if (!st.fail) {
+        for (i = 0; i < a->ntax; i++) if (!st.seen[i]) { p_fail(&st, "taxon missing from tree"); break; }
+    }
+    if (!st.fail && a->ntax < 3) p_fail(&st, "need at least 3 taxa");
+    if (!st.fail) {
+        while (st.n[root].nchild == 1) root = st.n[root].child[0];
+        t = t_alloc(a->ntax);
+        int next_inner = a->ntax;
+        pnode *r = &st.n[root];
+        if (r->nchild == 2) {
+            /* rooted: join the two root children by one branch */
+            int c0 = r->child[0], c1 = r->child[1];
+            double l = 0; int cc = c0; l += st.n[cc].len; while (st.n[cc].nchild == 1) { cc = st.n[cc].child[0]; l += st.n[cc].len; }
+            cc = c1; l += st.n[cc].len; while (st.n[cc].nchild == 1) { cc = st.n[cc].child[0]; l += st.n[cc].len; }
+            int a0 = t_build(&st, t, c0, &next_inner);
+            int a1 = t_build(&st, t, c1, &next_inner);
+            t_connect(t, a0, a1, l);
+        } else {
+            /* >=3 children: root becomes an inner node with 3 neighbours */
+            int nc = r->nchild; int id = next_inner++;
+            int *ids = (int *)malloc(sizeof(int) * nc); double *ls = (double *)malloc(sizeof(double) * nc);
+            for (i = 0; i < nc; i++) {
+                int c = st.n[root].child[i]; double l = st.n[c].len; int cc = c;
+                while (st.n[cc].nchild == 1) { cc = st.n[cc].child[0]; l += st.n[cc].len; }
+                ls[i] = l; ids[i] = t_build(&st, t, c, &next_inner);
+            }
+            int cur = ids[0]; double curl = ls[0];
+            for (i = 1; i < nc - 2; i++) {
+                int nid = next_inner++;
+                t_connect(t, nid, cur, curl); t_connect(t, nid, ids[i], ls[i]);
+                cur = nid; curl = PO_TMIN;
+            }
+            t_connect(t, id, cur, curl); t_connect(t, id, ids[nc - 2], ls[nc - 2]); t_connect(t, id, ids[nc - 1], ls[nc - 1]);
+            free(ids); free(ls);
+        }
+        if (next_inner != t->nnodes) { p_fail(&st, "internal: node count mismatch"); po_tree_free(t); t = NULL; }
+    }
+    for (i = 0; i < st.nn; i++) free(st.n[i].child);
+    free(st.n); free(st.seen);
+    if (t) for (i = 0; i < t->nnodes; i++) for (int k = 0; k < 3; k++) if (t->nbr[i][k] >= 0) {
+        if (!(t->len[i][k] >= 0)) t->len[i][k] = 0; if (t->len[i][k] > PO_TMAX) t->len[i][k] = PO_TMAX;
+    }
+    return t;
+}
+po_tree *po_tree_copy(const po_tree *s) {
+    po_tree *t = t_alloc(s->ntax);
+    memcpy(t->nbr, s->nbr, sizeof(int[3]) * s->nnodes); memcpy(t->len, s->len, sizeof(double[3]) * s->nnodes);
+    return t;
+}
+void po_tree_free(po_tree *t) { if (!t) return; free(t->nbr); free(t->len); free(t); }
+double po_tree_length(const po_tree *t) {
+    double s = 0; for (int i = 0; i < t->nnodes; i++) for (int k = 0; k < 3; k++) if (t->nbr[i][k] > i) s += t->len[i][k];
+    return s;
+}
+
+typedef struct { char *s; size_t n, cap; } sbuf;
+static void sb_add(sbuf *b, const char *x) {
+    size_t l = strlen(x);
+    if (b->n + l + 1 > b->cap) { b->cap = 2 * (b->n + l + 1); b->s = (char *)realloc(b->s, b->cap); }
+    memcpy(b->s + b->n, x, l + 1); b->n += l;
+}
+static void nw_rec(const po_tree *t, const po_aln *a, int v, int from, double len, int digits, sbuf *b) {
+    char tmp[64];
+    if (v < t->ntax) sb_add(b, a->names[v]);
+    else {
+        int first = 1; sb_add(b, "(");
+        for (int k = 0; k < 3; k++) { int w = t->nbr[v][k]; if (w < 0 || w == from) continue; if (!first) sb_add(b, ","); first = 0; nw_rec(t, a, w, v, t->len[v][k], digits, b); }
+        sb_add(b, ")");
+    }
+    snprintf(tmp, sizeof tmp, ":%.*f", digits, len); sb_add(b, tmp);
+}
+char *po_tree_newick(const po_tree *t, const po_aln *a, int digits) {
+    sbuf b = {0, 0, 0}; char tmp[64];
+    int r = t->nbr[0][0];                   /* inner neighbour of taxon 0 (ntax>=3) */
+    sb_add(&b, "("); sb_add(&b, a->names[0]); snprintf(tmp, sizeof tmp, ":%.*f", digits, t->len[0][0]); sb_add(&b, tmp);
+    for (int k = 0; k < 3; k++) { int w = t->nbr[r][k]; if (w < 0 || w == 0) continue; sb_add(&b, ","); nw_rec(t, a, w, r, t->len[r][k], digits, &b); }
+    sb_add(&b, ");");
+    return b.s;
+}
+
+/* bipartitions: bitset of taxa on the side NOT containing taxon 0 */
+static void bip_rec(const po_tree *t, int v, int from, unsigned long long *sets, int words, int *count, unsigned long long *out) {
+    memset(out, 0, sizeof(unsigned long long) * words);
+    if (v < t->ntax) { out[v >> 6] |= 1ULL << (v & 63); return; }
+    unsigned long long *tmp = (unsigned long long *)malloc(sizeof(unsigned long long) * words);
+    for (int k = 0; k < 3; k++) { int w = t->nbr[v][k]; if (w < 0 || w == from) continue; bip_rec(t, w, v, sets, words, count, tmp); for (int i = 0; i < words; i++) out[i] |= tmp[i]; }
+    free(tmp);
+    if (from >= t->ntax || from < 0) { /* internal edge (v,from) with from inner */ }
+    if (from >= t->ntax) { memcpy(sets + (size_t)(*count) * words, out, sizeof(unsigned long long) * words); (*count)++; }
+}
+static int g_words;
+static int bip_cmp(const void *a, const void *b) { return memcmp(a, b, sizeof(unsigned long long) * g_words); }
+static unsigned long long *tree_bips(const po_tree *t, int *count) {
+    int words = (t->ntax + 63) / 64;
+    unsigned long long *sets = (unsigned long long *)calloc((size_t)(t->nnodes) * words, sizeof(unsigned long long));
+    unsigned long long *out = (unsigned long long *)malloc(sizeof(unsigned long long) * words);
+    *count = 0;
+    int r = t->nbr[0][0];
+    for (int k = 0; k < 3; k++) { int w = t->nbr[r][k]; if (w < 0 || w == 0) continue; bip_rec(t, w, r, sets, words, count, out); }
+    free(out);
+    g_words = words; qsort(sets, *count, sizeof(unsigned long long) * words, bip_cmp);
+    return sets;
+}
+int po_tree_rf(const po_tree *a, const po_tree *b) {
+    int na, nb, words = (a->ntax + 63) / 64;
+    unsigned long long *sa = tree_bips(a, &na), *sb = tree_bips(b, &nb);
+    int i = 0, j = 0, common = 0; g_words = words;
+    while (i < na && j < nb) {
+        int c = bip_cmp(sa + (size_t)i * words, sb + (size_t)j * words);
+        if (c == 0) { common++; i++; j++; } else if (c < 0) i++; else j++;
+    }
+    free(sa); free(sb);
+    return (na + nb - 2 * common) / 2;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * likelihood engine: directional CLVs  D(v -> nbr k) with lazy validity
+ * ---------------------------------------------------------------------------------------- */
+struct po_engine {
+    const po_aln *a; const po_model *m;
+    int K; double alpha; double rates[PO_MAXCAT];
+    int ntax, npat, nnodes;
+    double **clv;      /* [ (v-ntax)*3 + k ] -> npat*K*20 doubles, layout [pat][cat][state] */
+    int **scl;         /* per-pattern cumulative scaling counts */
+    unsigned char *valid;
+    const po_tree *bound;   /* tree the cache refers to */
+    double tipvec[PO_NCODES][PO_NS];
+    double *sumtab;    /* npat*K*20 */
+    long n_newview, n_evaluate, n_deriv;
+};
+
+po_engine *po_engine_create(const po_aln *a, const po_model *m, int ncat, double alpha) {
+    po_engine *e = (po_engine *)calloc(1, sizeof(po_engine));
+    e->a = a; e->m = m; e->K = ncat; e->ntax = a->ntax; e->npat = a->npat; e->nnodes = 2 * a->ntax - 2;
+    int nd = (e->nnodes - e->ntax) * 3;
+    e->clv = (double **)calloc(nd, sizeof(double *)); e->scl = (int **)calloc(nd, sizeof(int *));
+    e->valid = (unsigned char *)calloc(nd, 1);
+    for (int c = 0; c < PO_NCODES; c++) { unsigned mk = po_code_mask(c); for (int s = 0; s < 20; s++) e->tipvec[c][s] = (mk >> s) & 1 ? 1.0 : 0.0; }
+    e->sumtab = (double *)malloc(sizeof(double) * (size_t)(e->npat > 0 ? e->npat : 1) * ncat * 20);
+    po_engine_set_alpha(e, alpha);
+    return e;
+}
+void po_engine_free(po_engine *e) {
+    if (!e) return;
+    int nd = (e->nnodes - e->ntax) * 3;
+    for (int i = 0; i < nd; i++) { free(e->clv[i]); free(e->scl[i]); }
+    free(e->clv); free(e->scl); free(e->valid); free(e->sumtab); free(e);
+}
+static void eng_invalidate_all(po_engine *e) { memset(e->valid, 0, (size_t)(e->nnodes - e->ntax) * 3); }
+void po_engine_set_alpha(po_engine *e, double alpha) {
+    if (alpha < PO_ALPHA_MIN) alpha = PO_ALPHA_MIN; if (alpha > PO_ALPHA_MAX) alpha = PO_ALPHA_MAX;
+    e->alpha = alpha; po_gamma_rates(alpha, e->K, 0, e->rates); eng_invalidate_all(e);
+}
+double po_engine_alpha(const po_engine *e) { return e->alpha; }
+
+static int slot_of(const po_tree *t, int v, int w) { for (int k = 0; k < 3; k++) if (t->nbr[v][k] == w) return k; return -1; }
+
+/* after the length of (a,b) changed (or topology changed around it): everything that "sees"
+ * the branch from outside becomes stale */
+static void eng_invalidate_from(po_engine *e, const po_tree *t, int v, int from) {
+    if (v < e->ntax) return;
+    for (int k = 0; k < 3; k++) {
+        int w = t->nbr[v][k]; if (w == from || w < 0) continue;
+        e->valid[(v - e->ntax) * 3 + k] = 0;
+        eng_invalidate_from(e, t, w, v);
+    }
+}
+static void eng_branch_changed(po_engine *e, const po_tree *t, int a, int b) {
+    eng_invalidate_from(e, t, a, b); eng_invalidate_from(e, t, b, a);
+}
+
+/* x[cat][s] = sum_j P_cat[s][j] * child[cat][j]  for one pattern */
+static void eng_newview(po_engine *e, const po_tree *t, int v, int k);
+
+typedef struct { const double *clv; const int *scl; const unsigned char *codes; } side;
+static side eng_side(po_engine *e, const po_tree *t, int v, int to) {
+    /* the message from v towards `to` */
+    side s = {0, 0, 0};
+    if (v < e->ntax) { s.codes = e->a->codes + (size_t)v * e->npat; return s; }
+    int k = slot_of(t, v, to);
+    if (!e->valid[(v - e->ntax) * 3 + k]) eng_newview(e, t, v, k);
+    s.clv = e->clv[(v - e->ntax) * 3 + k]; s.scl = e->scl[(v - e->ntax) * 3 + k];
+    return s;
+}
+static void eng_pmats(const po_engine *e, double t, double P[][PO_NS][PO_NS]) {
+    for (int c = 0; c < e->K; c++) po_pmatrix(e->m, t * e->rates[c], P[c]);
+}
+static void eng_newview(po_engine *e, const po_tree *t, int v, int k) {
+    int idx = (v - e->ntax) * 3 + k, K = e->K, np = e->npat;
+    int ch[2], ci = 0; double bl[2];
+    for (int q = 0; q < 3; q++) if (q != k) { ch[ci] = t->nbr[v][q]; bl[ci] = t->len[v][q]; ci++; }
+    side L = eng_side(e, t, ch[0], v), R = eng_side(e, t, ch[1], v);
+    if (!e->clv[idx]) { e->clv[idx] = (double *)malloc(sizeof(double) * (size_t)np * K * 20); e->scl[idx] = (int *)malloc(sizeof(int) * np); }
+    double (*PL)[PO_NS][PO_NS] = (double (*)[PO_NS][PO_NS])malloc(sizeof(double[PO_NS][PO_NS]) * K);
+    double (*PR)[PO_NS][PO_NS] = (double (*)[PO_NS][PO_NS])malloc(sizeof(double[PO_NS][PO_NS]) * K);
+    eng_pmats(e, bl[0], PL); eng_pmats(e, bl[1], PR);
+    double *out = e->clv[idx]; int *osc = e->scl[idx];
+    const double two256 = ldexp(1.0, 256), thresh = ldexp(1.0, -256);
+    for (int p = 0; p < np; p++) {
+        double mx = 0.0;
+        for (int c = 0; c < K; c++) {
+            const double *xl = L.clv ? L.clv + ((size_t)p * K + c) * 20 : e->tipvec[L.codes[p]];
+            const double *xr = R.clv ? R.clv + ((size_t)p * K + c) * 20 : e->tipvec[R.codes[p]];
+            double *o = out + ((size_t)p * K + c) * 20;
+            for (int s = 0; s < 20; s++) {
+                double a = 0, b = 0;
+                for (int j = 0; j < 20; j++) { a += PL[c][s][j] * xl[j]; b += PR[c][s][j] * xr[j]; }
+                o[s] = a * b; if (o[s] > mx) mx = o[s];
+            }
+        }
+        int sc = (L.scl ? L.scl[p] : 0) + (R.scl ? R.scl[p] : 0);
+        if (mx < thresh) { double *o = out + (size_t)p * K * 20; for (int q = 0; q < K * 20; q++) o[q] *= two256; sc++; }
+        osc[p] = sc;
+    }
+    free(PL); free(PR);
+    e->valid[idx] = 1; e->n_newview++;
+}
+static void eng_bind(po_engine *e, const po_tree *t) { if (e->bound != t) { e->bound = t; eng_invalidate_all(e); } }
+
+/* lnL evaluated on branch (u,v) */
+static double eng_evaluate(po_engine *e, const po_tree *t, int u, int v, double *pat_lnl) {
+    int K = e->K, np = e->npat;
+    side A = eng_side(e, t, u, v), B = eng_side(e, t, v, u);
+    double bl = t->len[u][slot_of(t, u, v)];
+    double (*P)[PO_NS][PO_NS] = (double (*)[PO_NS][PO_NS])malloc(sizeof(double[PO_NS][PO_NS]) * K);
+    eng_pmats(e, bl, P);
+    double total = 0;
+    for (int p = 0; p < np; p++) {
+        double site = 0;
+        for (int c = 0; c < K; c++) {
+            const double *xa = A.clv ? A.clv + ((size_t)p * K + c) * 20 : e->tipvec[A.codes[p]];
+            const double *xb = B.clv ? B.clv + ((size_t)p * K + c) * 20 : e->tipvec[B.codes[p]];
+            double cat = 0;
+            for (int s = 0; s < 20; s++) { double y = 0; for (int j = 0; j < 20; j++) y += P[c][s][j] * xb[j]; cat += e->m->pi[s] * xa[s] * y; }
+            site += cat;
+        }
+        site /= K;
+        int sc = (A.scl ? A.scl[p] : 0) + (B.scl ? B.scl[p] : 0);
+        double l = log(site) - sc * PO_LOG_2_256;
+        if (pat_lnl) pat_lnl[p] = l;
+        total += e->a->weight[p] * l;
+    }
+    free(P); e->n_evaluate++;
+    return total;
+}
+double po_engine_lnl(po_engine *e, const po_tree *t, double *pat_lnl) {
+    eng_bind(e, t);
+    return eng_evaluate(e, t, 0, t->nbr[0][0], pat_lnl);
+}
+double po_engine_site_lnl(po_engine *e, const po_tree *t, double *site_lnl) {
+    double *pl = (double *)malloc(sizeof(double) * (e->npat > 0 ? e->npat : 1));
+    double tot = po_engine_lnl(e, t, pl);
+    for (int s = 0; s < e->a->nsites; s++) site_lnl[s] = pl[e->a->site2pat[s]];
+    free(pl); return tot;
+}
+
+/* sumtable for branch (u,v): S[p][c][i] = (sum_s pi_s A[s] U[s][i]) * (sum_j Uinv[i][j] B[j]) */
+static void eng_sumtable(po_engine *e, const po_tree *t, int u, int v, int *scale_out) {
+    int K = e->K, np = e->npat;
+    side A = eng_side(e, t, u, v), B = eng_side(e, t, v, u);
+    for (int p = 0; p < np; p++) {
+        for (int c = 0; c < K; c++) {
+            const double *xa = A.clv ? A.clv + ((size_t)p * K + c) * 20 : e->tipvec[A.codes[p]];
+            const double *xb = B.clv ? B.clv + ((size_t)p * K + c) * 20 : e->tipvec[B.codes[p]];
+            double *o = e->sumtab + ((size_t)p * K + c) * 20;
+            for (int i = 0; i < 20; i++) {
+                double l = 0, r = 0;
+                for (int s = 0; s < 20; s++) { l += e->m->pi[s] * xa[s] * e->m->U[s][i]; r += e->m->Uinv[i][s] * xb[s]; }
+                o[i] = l * r;
+            }
+        }
+        if (scale_out) scale_out[p] = (A.scl ? A.scl[p] : 0) + (B.scl ? B.scl[p] : 0);
+    }
+}
+/* lnL (without scaling constant), d1, d2 at branch length tt from the sumtable */
+static void eng_core_derivs(po_engine *e, double tt, const int *scale, double *lnl, double *d1, double *d2) {
+    int K = e->K, np = e->npat;
+    double ex[PO_MAXCAT][PO_NS], g1[PO_MAXCAT][PO_NS], g2[PO_MAXCAT][PO_NS];
+    for (int c = 0; c < K; c++) for (int i = 0; i < 20; i++) {
+        double lr = e->m->eval[i] * e->rates[c];
+        ex[c][i] = exp(lr * tt); g1[c][i] = lr * ex[c][i]; g2[c][i] = lr * lr * ex[c][i];
+    }
+    double L = 0, D1 = 0, D2 = 0;
+    for (int p = 0; p < np; p++) {
+        double f = 0, f1 = 0, f2 = 0;
+        const double *s = e->sumtab + (size_t)p * K * 20;
+        for (int c = 0; c < K; c++) for (int i = 0; i < 20; i++) { double x = s[c * 20 + i]; f += x * ex[c][i]; f1 += x * g1[c][i]; f2 += x * g2[c][i]; }
+        double w = e->a->weight[p], r1 = f1 / f;
+        L += w * (log(f / K) - (scale ? scale[p] * PO_LOG_2_256 : 0.0));
+        D1 += w * r1; D2 += w * (f2 / f - r1 * r1);
+    }
+    *lnl = L; *d1 = D1; *d2 = D2; e->n_deriv++;
+}
+void po_engine_branch_derivs(po_engine *e, const po_tree *t, int u, int v, double *lnl, double *d1, double *d2) {
+    eng_bind(e, t);
+    int *sc = (int *)malloc(sizeof(int) * (e->npat > 0 ? e->npat : 1));
+    eng_sumtable(e, t, u, v, sc);
+    eng_core_derivs(e, t->len[u][slot_of(t, u, v)], sc, lnl, d1, d2);
+    free(sc);
+}
+
+/* Newton-Raphson on one branch with step control; returns new length.
+ * Spec (mirrored by the HIP engine, see DESIGN.md "branch Newton"):
+ *   t0 = clamp(t); up to 32 iterations: (L,d1,d2) at t; if d2<0 step=-d1/d2 else step = d1>0 ? t : -t/2;
+ *   tn = clamp(t+step, TMIN, TMAX); backtrack (halve step, <=8x) while L(tn) < L(t) - 1e-9;
+ *   stop when |tn-t| < 1e-8 */
+static double eng_newton_branch(po_engine *e, double t0, double *lnl_out) {
+    double t = t0 < PO_TMIN ? PO_TMIN : (t0 > PO_TMAX ? PO_TMAX : t0);
+    double L, d1, d2;
+    eng_core_derivs(e, t, NULL, &L, &d1, &d2);
+    for (int it = 0; it < 32; it++) {
+        double step = (d2 < 0) ? -d1 / d2 : (d1 > 0 ? t : -0.5 * t);
+        double tn = t + step, Ln, n1, n2; int bt = 0;
+        for (;;) {
+            if (tn < PO_TMIN) tn = PO_TMIN; if (tn > PO_TMAX) tn = PO_TMAX;
+            eng_core_derivs(e, tn, NULL, &Ln, &n1, &n2);
+            if (Ln >= L - 1e-9 || bt >= 8) break;
+            bt++; tn = 0.5 * (tn + t);
+        }
+        if (Ln < L - 1e-9) break;            /* could not improve: keep t */
+        double dt = fabs(tn - t);
+        t = tn; L = Ln; d1 = n1; d2 = n2;
+        if (dt < 1e-8) break;
+    }
+    if (lnl_out) *lnl_out = L;
+    return t;
+}
+static void tree_set_len(po_tree *t, int u, int v, double l) { t->len[u][slot_of(t, u, v)] = l; t->len[v][slot_of(t, v, u)] = l; }
+
+static void eng_smooth_rec(po_engine *e, po_tree *t, int v, int from, double *maxdelta) {
+    for (int k = 0; k < 3; k++) {
+        int w = t->nbr[v][k]; if (w < 0 || w == from) continue;
+        eng_sumtable(e, t, v, w, NULL);
+        double old = t->len[v][k], nl = eng_newton_branch(e, old, NULL);
+        if (fabs(nl - old) > *maxdelta) *maxdelta = fabs(nl - old);
+        if (nl != old) { tree_set_len(t, v, w, nl); eng_branch_changed(e, t, v, w); }
+        if (w >= e->ntax) eng_smooth_rec(e, t, w, v, maxdelta);
+    }
+}
+/* one smoothing pass over all branches, DFS from taxon 0 */
+static double eng_smooth(po_engine *e, po_tree *t) {
+    double md = 0; eng_smooth_rec(e, t, 0, -1, &md); return md;
+}
+
+/* Brent maximisation of lnL over alpha on log scale */
+static double eng_alpha_obj(po_engine *e, po_tree *t, double la) { po_engine_set_alpha(e, exp(la)); return -po_engine_lnl(e, t, NULL); }
+static double eng_opt_alpha(po_engine *e, po_tree *t) {
+    const double gold = 0.3819660112501051, tol = 1e-4;
+    double a = log(PO_ALPHA_MIN), b = log(PO_ALPHA_MAX);
+    double x = log(e->alpha), w = x, v = x, fx = eng_alpha_obj(e, t, x), fw = fx, fv = fx, d = 0, ee = 0;
+    /* shrink bracket around current alpha to speed up: +-ln(4) window, widened if at edge */
+    for (int it = 0; it < 60; it++) {
+        double xm = 0.5 * (a + b), tol1 = tol * fabs(x) + 1e-6, tol2 = 2 * tol1;
+        if (fabs(x - xm) <= tol2 - 0.5 * (b - a)) break;
+        int golden = 1; double u;
+        if (fabs(ee) > tol1) {
+            double r = (x - w) * (fx - fv), q = (x - v) * (fx - fw), p = (x - v) * q - (x - w) * r;
+            q = 2 * (q - r); if (q > 0) p = -p; q = fabs(q);
+            double etemp = ee; ee = d;
+            if (!(fabs(p) >= fabs(0.5 * q * etemp) || p <= q * (a - x) || p >= q * (b - x))) {
+                d = p / q; u = x + d; if (u - a < tol2 || b - u < tol2) d = (xm - x >= 0) ? tol1 : -tol1; golden = 0;
+            }
+        }
+        if (golden) { ee = (x >= xm) ? a - x : b - x; d = gold * ee; }
+        u = (fabs(d) >= tol1) ? x + d : x + (d >= 0 ? tol1 : -tol1);
+        double fu = eng_alpha_obj(e, t, u);
+        if (fu <= fx) { if (u >= x) a = x; else b = x; v = w; fv = fw; w = x; fw = fx; x = u; fx = fu; }
+        else { if (u < x) a = u; else b = u; if (fu <= fw || w == x) { v = w; fv = fw; w = u; fw = fu; } else if (fu <= fv || v == x || v == w) { v = u; fv = fu; } }
+    }
+    po_engine_set_alpha(e, exp(x));
+    return -fx;
+}
+
+double po_engine_optimize(po_engine *e, po_tree *t, int opt_alpha, double eps) {
+    eng_bind(e, t);
+    for (int i = 0; i < t->nnodes; i++) for (int k = 0; k < 3; k++) if (t->nbr[i][k] >= 0 && t->len[i][k] < PO_TMIN) t->len[i][k] = PO_TMIN;
+    eng_invalidate_all(e);
+    double lnl = po_engine_lnl(e, t, NULL);
+    for (int round = 0; round < 100; round++) {
+        for (int pass = 0; pass < 16; pass++) { if (eng_smooth(e, t) < 1e-6) break; }
+        double nl = opt_alpha ? eng_opt_alpha(e, t) : po_engine_lnl(e, t, NULL);
+        double gain = nl - lnl; lnl = nl;
+        if (gain < eps) break;
+    }
+    return lnl;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * brute force
+ * ---------------------------------------------------------------------------------------- */
+double po_bruteforce_lnl(const po_aln *a, const po_model *m, int K, double alpha, const po_tree *t) {
+    int ninner = t->nnodes - t->ntax, ne = 0;
+    if (ninner > 4) return NAN;
+    double rates[PO_MAXCAT]; po_gamma_rates(alpha, K, 0, rates);
+    int eu[16], ev[16]; double el[16];
+    for (int i = 0; i < t->nnodes; i++) for (int k = 0; k < 3; k++) if (t->nbr[i][k] > i) { eu[ne] = i; ev[ne] = t->nbr[i][k]; el[ne] = t->len[i][k]; ne++; }
+    long nassign = 1; for (int i = 0; i < ninner; i++) nassign *= 20;
+    double total = 0;
+    double (*P)[PO_NS][PO_NS] = (double (*)[PO_NS][PO_NS])malloc(sizeof(double[PO_NS][PO_NS]) * ne);
+    for (int p = 0; p < a->npat; p++) {
+        double site = 0;
+        for (int c = 0; c < K; c++) {
+            for (int q = 0; q < ne; q++) po_pmatrix(m, el[q] * rates[c], P[q]);
+            double cat = 0;
+            for (long as = 0; as < nassign; as++) {
+                int st[8]; long x = as; for (int i = 0; i < ninner; i++) { st[i] = (int)(x % 20); x /= 20; }
+                double pr = m->pi[st[0]];     /* root = first inner node */
+                /* orient edges away from inner node ntax by BFS order: since P reversible, use
+                 * pi_root * prod over edges P[parent][child] with orientation found by DFS */
+                int stack[16], par[16], sp = 0; stack[sp] = t->ntax; par[sp] = -1; sp++;
+                while (sp > 0 && pr > 0) {
+                    sp--; int v = stack[sp], pv = par[sp];
+                    for (int k = 0; k < 3; k++) {
+                        int w = t->nbr[v][k]; if (w < 0 || w == pv) continue;
+                        int q; for (q = 0; q < ne; q++) if ((eu[q] == v && ev[q] == w) || (eu[q] == w && ev[q] == v)) break;
+                        if (w >= t->ntax) { pr *= P[q][st[v - t->ntax]][st[w - t->ntax]]; stack[sp] = w; par[sp] = v; sp++; }
+                        else { unsigned mk = po_code_mask(a->codes[(size_t)w * a->npat + p]); double s = 0; for (int j = 0; j < 20; j++) if ((mk >> j) & 1) s += P[q][st[v - t->ntax]][j]; pr *= s; }
+                    }
+                }
+                cat += pr;
+            }
+            site += cat / K;
+        }
+        total += a->weight[p] * log(site);
+    }
+    free(P);
+    return total;
+}
