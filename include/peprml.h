@@ -1,0 +1,142 @@
+/*
+ * peprml.h -- C ABI of libpeprml.so, the MI355X-native maximum-likelihood tree engine that
+ * replaces the external-process calls on PEPR's tree-building path.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the PEPR
+ * repository, src/edu/vt/vbi/ci/ abbreviated as .../):
+ *
+ *   pml_score      <- .../pepr/tree/RAxMLRunner.java:162-213   runRaxmlPerSiteLL():
+ *                        `raxmlHPC -f g -m PROTGAMMAWAG -z trees -s aln` -> RAxML_perSiteLLs.<run>
+ *   pml_optimize   <- .../pepr/tree/FastTreeRunner.java:142-199 getRaxmlBranchLengths() and
+ *                     .../pepr/tree/RAxMLRunner.java:253-272:  `raxmlHPC -f e -t tree` -> RAxML_result.<run>
+ *   pml_search     <- .../pepr/tree/RAxMLRunner.java:79-152     run():  `raxmlHPC -f d -m PROTGAMMAWAG`
+ *                     .../pepr/tree/FastTreeRunner.java:38-135  run():  `FastTree_WAG -gamma -nosupport`
+ *   pml_*_batch    <- .../pepr/tree/pipeline/PhylogenomicPipeline2.java:1587-1633
+ *                        GeneSubsetTreeRunnable.run(): the data-parallel loop of independent tree builds
+ *   pml_rf_distance<- .../pepr/tree/AdvancedTree.java:1460-1491 (Robinson-Foulds used for acceptance)
+ *
+ * Conventions: caller owns inputs (nothing is retained after return);
+ * the library allocates results, the caller releases them with pml_result_free(); no files, no
+ * cwd dependence, no stdout/stderr output; every function returns 0 or a negative PML_E* code and
+ * never aborts or throws.  A context may be used from several threads: calls serialise on it.
+ * The alignment rows are exactly SequenceAlignment.alignedSequenceChars
+ * (.../pepr/alignment/SequenceAlignment.java:61): one char row per taxon, 20 amino-acid letters,
+ * '-' gap, '?' absent gene, anything else unknown (treated like a gap; B/Z are N|D and Q|E).
+ *
+ * There is NO CPU fallback: without a HIP device pml_create() fails with PML_ENODEVICE.
+ */
+#ifndef PEPRML_H
+#define PEPRML_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PML_OK          0
+#define PML_EINVAL     -1   /* bad argument */
+#define PML_EPARSE     -2   /* Newick / alignment parse error (message in pml_last_error) */
+#define PML_ENODEVICE  -3   /* no usable HIP device */
+#define PML_ENOMEM     -4   /* host or device allocation failed */
+#define PML_EDEVICE    -5   /* HIP runtime error */
+#define PML_ENOTFOUND  -6
+
+typedef struct pml_ctx pml_ctx;
+typedef struct pml_batch pml_batch;
+
+typedef struct {
+    int device;              /* HIP device ordinal (rank-local GPU) */
+    int profile;             /* 1: record HIP events around kernels (pml_kernel_stats) */
+    size_t arena_bytes;      /* 0 = size automatically per batch */
+} pml_config;
+
+typedef struct {
+    int ntax;
+    int nsites;
+    const char *const *names;   /* ntax taxon names (Newick leaf labels) */
+    const char *const *rows;    /* ntax rows of nsites chars */
+} pml_alignment;
+
+enum { PML_PI_RAXML_3DP = 0, PML_PI_WAG_FULL = 1 };
+
+typedef struct {
+    int ncat;                /* Gamma categories (4 = RAxML PROTGAMMA; 1 = no rate heterogeneity) */
+    double alpha;            /* Gamma shape (start value when optimised) */
+    int pi_mode;             /* PML_PI_RAXML_3DP (RAxML 7.2.5 PROTGAMMAWAG) or PML_PI_WAG_FULL */
+} pml_model;
+
+typedef struct {
+    int optimize_alpha;      /* 1: Brent on alpha */
+    int nni;                 /* 1: NNI hill climbing */
+    int spr_radius;          /* >0: SPR rounds with this rearrangement radius */
+    double epsilon;          /* stop when a round gains less than this many lnL units */
+    unsigned seed;           /* reserved (search is deterministic) */
+} pml_search_opts;
+
+typedef struct {
+    int status;              /* PML_OK or error for this gene */
+    double lnl;              /* log likelihood */
+    double alpha;            /* Gamma shape used / found */
+    double tree_length;      /* sum of branch lengths */
+    int npatterns;           /* alignment patterns after compression */
+    int nsites;
+    char *newick;            /* resulting tree, NUL-terminated, RAxML-style unrooted (may be NULL) */
+    double *site_lnl;        /* per-site lnL in alignment column order (only if requested) */
+} pml_result;
+
+#define PML_WANT_SITE_LNL 1   /* flags for pml_score */
+
+/* lifecycle */
+int  pml_create(const pml_config *cfg, pml_ctx **out);
+void pml_destroy(pml_ctx *ctx);
+const char *pml_strerror(int code);
+const char *pml_last_error(pml_ctx *ctx);     /* detail of the last failure on this context */
+const char *pml_version(void);
+
+/* one-shot calls (one gene) */
+int pml_score(pml_ctx *ctx, const pml_alignment *aln, const char *newick, const pml_model *model,
+              int flags, pml_result *out);
+int pml_optimize(pml_ctx *ctx, const pml_alignment *aln, const char *newick, const pml_model *model,
+                 const pml_search_opts *opts, pml_result *out);
+int pml_search(pml_ctx *ctx, const pml_alignment *aln, const char *start_newick /* NULL = NJ */,
+               const pml_model *model, const pml_search_opts *opts, pml_result *out);
+
+/* gene-batched calls: n independent (alignment, tree) units evaluated together on the device */
+int pml_score_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks,
+                    const pml_model *model, int flags, pml_result *out);
+int pml_optimize_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks,
+                       const pml_model *model, const pml_search_opts *opts, pml_result *out);
+int pml_search_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *start_newicks,
+                     const pml_model *model, const pml_search_opts *opts, pml_result *out);
+void pml_result_free(pml_result *r);
+
+/* resident batches: encode + upload once, then evaluate repeatedly with inputs in HBM */
+int  pml_batch_create(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks,
+                      const pml_model *model, pml_batch **out);
+void pml_batch_destroy(pml_batch *b);
+int  pml_batch_size(const pml_batch *b);
+int  pml_batch_npatterns(const pml_batch *b, int gene);
+/* full post-order CLV pass + root evaluation for every gene (all CLVs recomputed) */
+int  pml_batch_score(pml_batch *b, double *lnl_out /* n */);
+int  pml_batch_site_lnl(pml_batch *b, int gene, double *site_lnl /* nsites */);
+int  pml_batch_set_alpha(pml_batch *b, int gene /* -1 = all */, double alpha);
+int  pml_batch_optimize(pml_batch *b, const pml_search_opts *opts, double *lnl_out, double *alpha_out);
+int  pml_batch_search(pml_batch *b, const pml_search_opts *opts, double *lnl_out, double *alpha_out);
+int  pml_batch_newick(pml_batch *b, int gene, int digits, char **out /* free with pml_free */);
+/* d lnL/dt, d2 lnL/dt2 for the branch above each gene's taxon 0 (test hook for the Newton kernel) */
+int  pml_batch_root_derivs(pml_batch *b, double *lnl, double *d1, double *d2);
+void pml_free(void *p);
+
+/* tree utilities (host) */
+int pml_rf_distance(const char *newick_a, const char *newick_b, int *rf_out);
+
+/* profiling: HIP-event time of device kernels since the last reset (cfg.profile = 1) */
+enum { PML_K_PMAT = 0, PML_K_NEWVIEW = 1, PML_K_EVALUATE = 2, PML_K_SUMTABLE = 3, PML_K_NEWTON = 4,
+       PML_K_REDUCE = 5, PML_K_COUNT = 6 };
+int pml_kernel_stats(pml_ctx *ctx, int kernel, long long *launches, double *total_ms,
+                     double *algo_bytes /* algorithmic bytes moved, SURVEY 8d figures */);
+int pml_kernel_stats_reset(pml_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

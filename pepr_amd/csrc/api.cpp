@@ -1,0 +1,261 @@
+// api.cpp -- the C ABI declared in include/peprml.h.  Nothing here computes likelihoods on the
+// CPU: every numeric result comes from the HIP kernels; without a device pml_create() fails.
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/peprml.h"
+#include "engine.hpp"
+
+using namespace pml;
+
+struct pml_ctx { Ctx c; };
+struct pml_batch { Batch b; pml_ctx *owner; };
+
+static thread_local std::string g_err;
+
+extern "C" {
+
+const char *pml_version(void) { return "peprml 0.1 (gfx950)"; }
+
+const char *pml_strerror(int code) {
+    switch (code) {
+        case PML_OK: return "ok";
+        case PML_EINVAL: return "invalid argument";
+        case PML_EPARSE: return "parse error";
+        case PML_ENODEVICE: return "no HIP device";
+        case PML_ENOMEM: return "out of memory";
+        case PML_EDEVICE: return "HIP runtime error";
+        case PML_ENOTFOUND: return "not found";
+        default: return "unknown error";
+    }
+}
+
+const char *pml_last_error(pml_ctx *ctx) { return ctx ? ctx->c.last_error.c_str() : g_err.c_str(); }
+
+int pml_create(const pml_config *cfg, pml_ctx **out) {
+    if (!out) return PML_EINVAL;
+    *out = nullptr;
+    pml_ctx *c = new (std::nothrow) pml_ctx();
+    if (!c) return PML_ENOMEM;
+    const int rc = c->c.init(cfg ? cfg->device : 0, cfg ? cfg->profile != 0 : false);
+    if (rc) { g_err = c->c.last_error; delete c; return rc; }
+    *out = c;
+    return PML_OK;
+}
+
+void pml_destroy(pml_ctx *ctx) {
+    if (!ctx) return;
+    ctx->c.destroy();
+    delete ctx;
+}
+
+void pml_free(void *p) { std::free(p); }
+
+void pml_result_free(pml_result *r) {
+    if (!r) return;
+    std::free(r->newick); std::free(r->site_lnl);
+    r->newick = nullptr; r->site_lnl = nullptr;
+}
+
+static char *dup_string(const std::string &s) {
+    char *p = (char *)std::malloc(s.size() + 1);
+    if (p) std::memcpy(p, s.c_str(), s.size() + 1);
+    return p;
+}
+
+// ---- resident batches ---------------------------------------------------------------------
+static int batch_create_impl(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks,
+                             const pml_model *model, bool score_only, pml_batch **out) {
+    if (!ctx || !out || !alns || n <= 0) return PML_EINVAL;
+    *out = nullptr;
+    pml_batch *b = new (std::nothrow) pml_batch();
+    if (!b) return PML_ENOMEM;
+    b->owner = ctx;
+    static_assert(sizeof(pml_alignment) == sizeof(pml_alignment_view), "alignment view layout");
+    const int ncat = model ? model->ncat : 4;
+    const double alpha = model ? model->alpha : 1.0;
+    const int pm = model ? model->pi_mode : PML_PI_RAXML_3DP;
+    int rc;
+    try {
+        rc = b->b.create(&ctx->c, n, reinterpret_cast<const pml_alignment_view *>(alns), newicks, pm, ncat, alpha, score_only);
+    } catch (const std::bad_alloc &) { rc = ctx->c.fail(PML_ENOMEM, "host allocation failed"); }
+    catch (const std::exception &e) { rc = ctx->c.fail(PML_EINVAL, e.what()); }
+    if (rc) { b->b.destroy(); delete b; return rc; }
+    *out = b;
+    return PML_OK;
+}
+
+int pml_batch_create(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks,
+                     const pml_model *model, pml_batch **out) {
+    if (!ctx) return PML_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->c.mu);
+    return batch_create_impl(ctx, n, alns, newicks, model, false, out);
+}
+
+void pml_batch_destroy(pml_batch *b) {
+    if (!b) return;
+    std::lock_guard<std::mutex> lk(b->owner->c.mu);
+    b->b.destroy();
+    delete b;
+}
+
+int pml_batch_size(const pml_batch *b) { return b ? (int)b->b.genes.size() : 0; }
+int pml_batch_npatterns(const pml_batch *b, int g) {
+    if (!b || g < 0 || g >= (int)b->b.genes.size()) return PML_EINVAL;
+    return b->b.genes[g].aln.npat;
+}
+
+#define LOCKED(b) std::lock_guard<std::mutex> lk((b)->owner->c.mu)
+#define GUARD(expr)                                                                            \
+    try { return (expr); }                                                                     \
+    catch (const std::bad_alloc &) { return b->owner->c.fail(PML_ENOMEM, "host allocation failed"); } \
+    catch (const std::exception &e) { return b->owner->c.fail(PML_EINVAL, e.what()); }
+
+int pml_batch_score(pml_batch *b, double *lnl) {
+    if (!b || !lnl) return PML_EINVAL;
+    LOCKED(b);
+    GUARD(b->b.score(std::vector<char>(), lnl));
+}
+int pml_batch_site_lnl(pml_batch *b, int g, double *out) {
+    if (!b || !out || g < 0 || g >= (int)b->b.genes.size()) return PML_EINVAL;
+    LOCKED(b);
+    GUARD(b->b.site_lnl(g, out));
+}
+int pml_batch_set_alpha(pml_batch *b, int g, double alpha) {
+    if (!b || g >= (int)b->b.genes.size() || !(alpha > 0)) return PML_EINVAL;
+    LOCKED(b);
+    if (g < 0) for (int i = 0; i < (int)b->b.genes.size(); ++i) b->b.set_alpha(i, alpha);
+    else b->b.set_alpha(g, alpha);
+    return PML_OK;
+}
+int pml_batch_root_derivs(pml_batch *b, double *lnl, double *d1, double *d2) {
+    if (!b || !lnl || !d1 || !d2) return PML_EINVAL;
+    LOCKED(b);
+    GUARD(b->b.root_derivs(lnl, d1, d2));
+}
+int pml_batch_optimize(pml_batch *b, const pml_search_opts *opts, double *lnl, double *alpha) {
+    if (!b || !lnl) return PML_EINVAL;
+    LOCKED(b);
+    const bool oa = opts ? opts->optimize_alpha != 0 : true;
+    const double eps = (opts && opts->epsilon > 0) ? opts->epsilon : 1e-4;
+    int rc;
+    try { rc = b->b.optimize(oa, eps, lnl); }
+    catch (const std::exception &e) { return b->owner->c.fail(PML_EINVAL, e.what()); }
+    if (rc) return rc;
+    if (alpha) for (size_t g = 0; g < b->b.genes.size(); ++g) alpha[g] = b->b.genes[g].alpha;
+    return PML_OK;
+}
+int pml_batch_search(pml_batch *b, const pml_search_opts *opts, double *lnl, double *alpha) {
+    if (!b || !lnl) return PML_EINVAL;
+    LOCKED(b);
+    int rc;
+    try { rc = b->b.search(opts ? opts->nni != 0 : true, opts ? opts->spr_radius : 0,
+                           opts ? opts->optimize_alpha != 0 : true,
+                           (opts && opts->epsilon > 0) ? opts->epsilon : 1e-3, lnl); }
+    catch (const std::exception &e) { return b->owner->c.fail(PML_EINVAL, e.what()); }
+    if (rc) return rc;
+    if (alpha) for (size_t g = 0; g < b->b.genes.size(); ++g) alpha[g] = b->b.genes[g].alpha;
+    return PML_OK;
+}
+int pml_batch_newick(pml_batch *b, int g, int digits, char **out) {
+    if (!b || !out || g < 0 || g >= (int)b->b.genes.size()) return PML_EINVAL;
+    LOCKED(b);
+    const Gene &G = b->b.genes[g];
+    *out = dup_string(G.tree.newick(G.aln.names, digits));
+    return *out ? PML_OK : PML_ENOMEM;
+}
+
+// ---- one-shot wrappers --------------------------------------------------------------------
+enum { OP_SCORE, OP_OPTIMIZE, OP_SEARCH };
+
+static int oneshot(pml_ctx *ctx, int op, int n, const pml_alignment *alns, const char *const *newicks,
+                   const pml_model *model, const pml_search_opts *opts, int flags, pml_result *out) {
+    if (!ctx || !alns || !out || n <= 0) return PML_EINVAL;
+    for (int i = 0; i < n; ++i) std::memset(&out[i], 0, sizeof(pml_result));
+    if (op != OP_SEARCH) {
+        if (!newicks) return ctx->c.fail(PML_EINVAL, "newick required");
+        for (int i = 0; i < n; ++i) if (!newicks[i]) return ctx->c.fail(PML_EINVAL, "newick required");
+    }
+    std::lock_guard<std::mutex> lk(ctx->c.mu);
+    pml_batch *b = nullptr;
+    int rc = batch_create_impl(ctx, n, alns, newicks, model, op == OP_SCORE, &b);
+    if (rc) { for (int i = 0; i < n; ++i) out[i].status = rc; return rc; }
+    std::vector<double> lnl(n);
+    try {
+        if (op == OP_SCORE) rc = b->b.score(std::vector<char>(), lnl.data());
+        else if (op == OP_OPTIMIZE)
+            rc = b->b.optimize(opts ? opts->optimize_alpha != 0 : true, (opts && opts->epsilon > 0) ? opts->epsilon : 1e-4, lnl.data());
+        else
+            rc = b->b.search(opts ? opts->nni != 0 : true, opts ? opts->spr_radius : 0, opts ? opts->optimize_alpha != 0 : true,
+                             (opts && opts->epsilon > 0) ? opts->epsilon : 1e-3, lnl.data());
+        for (int i = 0; i < n && !rc; ++i) {
+            const Gene &G = b->b.genes[i];
+            pml_result &r = out[i];
+            r.lnl = lnl[i]; r.alpha = G.alpha; r.tree_length = G.tree.length();
+            r.npatterns = G.aln.npat; r.nsites = G.aln.nsites;
+            r.newick = dup_string(G.tree.newick(G.aln.names, op == OP_SCORE ? 10 : 20));
+            if (op == OP_SCORE && (flags & PML_WANT_SITE_LNL)) {
+                r.site_lnl = (double *)std::malloc(sizeof(double) * (G.aln.nsites > 0 ? G.aln.nsites : 1));
+                if (!r.site_lnl) rc = ctx->c.fail(PML_ENOMEM, "host allocation failed");
+                else rc = b->b.site_lnl(i, r.site_lnl);
+            }
+        }
+    } catch (const std::bad_alloc &) { rc = ctx->c.fail(PML_ENOMEM, "host allocation failed"); }
+    catch (const std::exception &e) { rc = ctx->c.fail(PML_EINVAL, e.what()); }
+    b->b.destroy(); delete b;
+    for (int i = 0; i < n; ++i) out[i].status = rc;
+    return rc;
+}
+
+int pml_score(pml_ctx *ctx, const pml_alignment *aln, const char *newick, const pml_model *model, int flags, pml_result *out) {
+    return oneshot(ctx, OP_SCORE, 1, aln, &newick, model, nullptr, flags, out);
+}
+int pml_optimize(pml_ctx *ctx, const pml_alignment *aln, const char *newick, const pml_model *model,
+                 const pml_search_opts *opts, pml_result *out) {
+    return oneshot(ctx, OP_OPTIMIZE, 1, aln, &newick, model, opts, 0, out);
+}
+int pml_search(pml_ctx *ctx, const pml_alignment *aln, const char *start, const pml_model *model,
+               const pml_search_opts *opts, pml_result *out) {
+    return oneshot(ctx, OP_SEARCH, 1, aln, start ? &start : nullptr, model, opts, 0, out);
+}
+int pml_score_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks, const pml_model *model,
+                    int flags, pml_result *out) {
+    return oneshot(ctx, OP_SCORE, n, alns, newicks, model, nullptr, flags, out);
+}
+int pml_optimize_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks,
+                       const pml_model *model, const pml_search_opts *opts, pml_result *out) {
+    return oneshot(ctx, OP_OPTIMIZE, n, alns, newicks, model, opts, 0, out);
+}
+int pml_search_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *starts,
+                     const pml_model *model, const pml_search_opts *opts, pml_result *out) {
+    return oneshot(ctx, OP_SEARCH, n, alns, starts, model, opts, 0, out);
+}
+
+int pml_rf_distance(const char *a, const char *b, int *rf) {
+    if (!a || !b || !rf) return PML_EINVAL;
+    try {
+        std::vector<std::string> na, nb; Tree ta, tb; std::string err;
+        if (!Tree::parse_free(a, na, ta, err)) { g_err = err; return PML_EPARSE; }
+        if (!Tree::parse(b, na, tb, err)) { g_err = err; return PML_EPARSE; }
+        *rf = rf_distance(ta, tb);
+    } catch (const std::exception &e) { g_err = e.what(); return PML_EINVAL; }
+    return PML_OK;
+}
+
+int pml_kernel_stats(pml_ctx *ctx, int k, long long *launches, double *ms, double *bytes) {
+    if (!ctx || k < 0 || k >= K_COUNT) return PML_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->c.mu);
+    if (launches) *launches = ctx->c.stats[k].launches;
+    if (ms) *ms = ctx->c.stats[k].ms;
+    if (bytes) *bytes = ctx->c.stats[k].bytes;
+    return PML_OK;
+}
+int pml_kernel_stats_reset(pml_ctx *ctx) {
+    if (!ctx) return PML_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->c.mu);
+    for (auto &s : ctx->c.stats) s = Ctx::KStat();
+    return PML_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,542 @@
+// engine.cpp -- batch engine: HBM arena, lazy directional-CLV bookkeeping, level-synchronous
+// newview scheduling across genes, branch-length / alpha optimisation drivers.
+//
+// Scheduling model (DESIGN.md "Scheduling"): every gene keeps one CLV per DIRECTED inner edge
+// ("message" v->w: likelihood of the subtree hanging off v when edge (v,w) is cut).  A request
+// (lnL, branch derivatives) names the messages it needs; need() walks the tree lazily and emits
+// the missing newviews in dependency levels; run() uploads all descriptors of all genes once,
+// launches k_pmat, one k_nv<NEWVIEW> per level, the tail kernels, and syncs once.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace pml {
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return ctx->fail(-5, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// Ctx
+// ------------------------------------------------------------------------------------------
+int Ctx::init(int dev, bool prof) {
+    Ctx *ctx = this;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(-3, "no HIP device available");
+    if (dev < 0 || dev >= count) return fail(-3, "device ordinal out of range");
+    device = dev; profile = prof;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    return 0;
+}
+void Ctx::destroy() {
+    hipSetDevice(device);
+    for (auto &e : pending) { pool.push_back(e.a); pool.push_back(e.b); }
+    pending.clear();
+    for (auto e : pool) hipEventDestroy(e);
+    pool.clear();
+    for (int i = 0; i < 2; ++i) { if (d_model[i]) hipFree(d_model[i]); if (d_eigfrags[i]) hipFree(d_eigfrags[i]); d_model[i] = nullptr; d_eigfrags[i] = nullptr; }
+    if (stream) hipStreamDestroy(stream);
+    stream = nullptr;
+}
+int Ctx::ensure_model(int pm) {
+    Ctx *ctx = this;
+    if (pm < 0 || pm > 1) return fail(-1, "bad pi_mode");
+    if (model_ready[pm]) return 0;
+    model[pm].init(pm);
+    ModelDev h;
+    std::memcpy(h.eval, model[pm].eval, sizeof h.eval);
+    std::memcpy(h.U, model[pm].U, sizeof h.U);
+    std::memcpy(h.Uinv, model[pm].Uinv, sizeof h.Uinv);
+    std::memcpy(h.pi, model[pm].pi, sizeof h.pi);
+    HIPCHK(hipMalloc(&d_model[pm], sizeof(ModelDev)));
+    HIPCHK(hipMalloc(&d_eigfrags[pm], sizeof(double) * 2 * PFRAG));
+    HIPCHK(hipMemcpy(d_model[pm], &h, sizeof h, hipMemcpyHostToDevice));
+    launch_eigfrags(d_model[pm], d_eigfrags[pm], stream);
+    HIPCHK(hipStreamSynchronize(stream));
+    model_ready[pm] = true;
+    return 0;
+}
+hipEvent_t Ctx::get_event() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+}
+void Ctx::tic(int kind, double bytes) {
+    stats[kind].launches++; stats[kind].bytes += bytes;
+    if (!profile) return;
+    Ev ev{kind, get_event(), get_event()};
+    hipEventRecord(ev.a, stream);
+    pending.push_back(ev);
+}
+void Ctx::toc() {
+    if (!profile) return;
+    hipEventRecord(pending.back().b, stream);
+}
+void Ctx::resolve_events() {
+    for (auto &e : pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) stats[e.kind].ms += ms;
+        pool.push_back(e.a); pool.push_back(e.b);
+    }
+    pending.clear();
+}
+
+// ------------------------------------------------------------------------------------------
+// Batch: creation / layout
+// ------------------------------------------------------------------------------------------
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *const *newicks, int pm, int nc,
+                  double alpha, bool score_only) {
+    ctx = c; pi_mode = pm; ncat = nc;
+    if (n <= 0) return ctx->fail(-1, "empty batch");
+    if (nc != 1 && nc != 4) return ctx->fail(-1, "ncat must be 1 or 4");
+    if (int rc = ctx->ensure_model(pm)) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    genes.resize(n);
+    std::string err;
+    size_t total = 0;
+    std::vector<size_t> off(n);
+    for (int g = 0; g < n; ++g) {
+        Gene &G = genes[g];
+        if (!G.aln.encode(alns[g].ntax, alns[g].nsites, alns[g].names, alns[g].rows, err))
+            return ctx->fail(-2, "gene " + std::to_string(g) + ": " + err);
+        if (newicks && newicks[g]) {
+            if (!Tree::parse(newicks[g], G.aln.names, G.tree, err)) return ctx->fail(-2, "gene " + std::to_string(g) + ": " + err);
+        } else {
+            G.tree = nj_tree(G.aln);
+        }
+        const int nt = G.aln.ntax, mp = G.aln.mpad, ndir = 3 * (nt - 2);
+        G.slot_cap = score_only ? (nt - 2) : ndir;
+        G.slot_of.assign(ndir, -1); G.valid.assign(ndir, 0); G.pend_level.assign(ndir, -1);
+        off[g] = total;
+        total += align_up((size_t)nt * mp, 256);                       // codes
+        total += align_up((size_t)mp * 8, 256);                        // weight
+        total += (size_t)G.slot_cap * CLV_ROWS * mp * 8;               // clv
+        total += align_up((size_t)G.slot_cap * mp * 4, 256);           // scalers
+        total += (size_t)CLV_ROWS * mp * 8;                            // sumtable
+        total += align_up((size_t)mp * 4, 256);                        // sumtable scalers
+        total += align_up((size_t)mp * 8, 256);                        // per-pattern lnL
+    }
+    arena_bytes = total;
+    if (hipMalloc((void **)&arena, total) != hipSuccess) {
+        arena = nullptr;
+        return ctx->fail(-4, "device arena of " + std::to_string(total >> 20) + " MiB does not fit");
+    }
+    for (int g = 0; g < n; ++g) {
+        Gene &G = genes[g];
+        const int nt = G.aln.ntax, mp = G.aln.mpad;
+        char *p = arena + off[g];
+        G.d_codes = (uint8_t *)p; p += align_up((size_t)nt * mp, 256);
+        G.d_weight = (double *)p; p += align_up((size_t)mp * 8, 256);
+        G.d_clv = (double *)p; p += (size_t)G.slot_cap * CLV_ROWS * mp * 8;
+        G.d_scl = (int *)p; p += align_up((size_t)G.slot_cap * mp * 4, 256);
+        G.d_sumtab = (double *)p; p += (size_t)CLV_ROWS * mp * 8;
+        G.d_sumscl = (int *)p; p += align_up((size_t)mp * 4, 256);
+        G.d_patlnl = (double *)p;
+        HIPCHK(hipMemcpyAsync(G.d_codes, G.aln.codes.data(), (size_t)nt * mp, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(G.d_weight, G.aln.weight.data(), (size_t)mp * 8, hipMemcpyHostToDevice, ctx->stream));
+        set_alpha(g, alpha);
+    }
+    HIPCHK(hipMalloc((void **)&d_scalars, sizeof(double) * 8 * n));
+    HIPCHK(hipHostMalloc((void **)&h_scalars, sizeof(double) * 8 * n));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+void Batch::destroy() {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (arena) hipFree(arena);
+    if (h_stage) hipHostFree(h_stage);
+    if (d_stage) hipFree(d_stage);
+    if (d_frags) hipFree(d_frags);
+    if (d_scalars) hipFree(d_scalars);
+    if (h_scalars) hipHostFree(h_scalars);
+    arena = nullptr; h_stage = d_stage = nullptr; d_frags = nullptr; d_scalars = h_scalars = nullptr;
+}
+
+int Batch::ensure_stage(size_t bytes) {
+    if (bytes <= h_cap) return 0;
+    const size_t cap = std::max(bytes * 3 / 2, (size_t)1 << 20);
+    if (h_stage) hipHostFree(h_stage);
+    if (d_stage) hipFree(d_stage);
+    h_stage = d_stage = nullptr; h_cap = d_cap = 0;
+    HIPCHK(hipHostMalloc(&h_stage, cap));
+    HIPCHK(hipMalloc(&d_stage, cap));
+    h_cap = d_cap = cap;
+    return 0;
+}
+int Batch::ensure_frags(size_t sets) {
+    if (sets <= frag_cap) return 0;
+    const size_t cap = std::max(sets * 5 / 4, (size_t)256);
+    if (d_frags) hipFree(d_frags);
+    d_frags = nullptr; frag_cap = 0;
+    HIPCHK(hipMalloc((void **)&d_frags, cap * PFRAG * sizeof(double)));
+    frag_cap = cap;
+    return 0;
+}
+
+void Batch::set_alpha(int g, double a) {
+    Gene &G = genes[g];
+    a = std::min(std::max(a, ALPHA_MIN), ALPHA_MAX);
+    G.alpha = a;
+    if (ncat == 1) { for (double &r : G.rates) r = 1.0; }
+    else gamma_rates(a, NCAT, G.rates);
+    invalidate_all(g);
+}
+void Batch::invalidate_all(int g) {
+    Gene &G = genes[g];
+    std::fill(G.valid.begin(), G.valid.end(), 0);
+    if (G.slot_cap < (int)G.slot_of.size()) { std::fill(G.slot_of.begin(), G.slot_of.end(), -1); G.next_slot = 0; }
+}
+static void invalidate_from(Gene &G, int v, int from) {
+    // iterative DFS: every message leaving v away from `from`, and onwards
+    std::vector<std::pair<int, int>> st{{v, from}};
+    const int nt = G.aln.ntax;
+    while (!st.empty()) {
+        auto [x, f] = st.back(); st.pop_back();
+        if (x < nt) continue;
+        for (int k = 0; k < 3; ++k) {
+            const int w = G.tree.nbr[x][k];
+            if (w == f || w < 0) continue;
+            G.valid[(x - nt) * 3 + k] = 0;
+            st.push_back({w, x});
+        }
+    }
+}
+void Batch::branch_changed(int g, int a, int b) {
+    invalidate_from(genes[g], a, b); invalidate_from(genes[g], b, a);
+}
+int Batch::slot_for(Gene &G, int idx) {
+    int s = G.slot_of[idx];
+    if (s < 0) { if (G.next_slot >= G.slot_cap) return -1; s = G.slot_of[idx] = G.next_slot++; }
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// lazy collection of the newviews a message depends on
+// ------------------------------------------------------------------------------------------
+int Batch::need(int g, int v, int to, std::vector<PendingOp> &ops) {
+    Gene &G = genes[g];
+    const int nt = G.aln.ntax;
+    if (v < nt) return 0;
+    // explicit stack (trees can be caterpillars of depth ~ntax)
+    struct Frame { int v, to, k, stage, lv[2]; };
+    std::vector<Frame> st;
+    st.push_back({v, to, G.tree.slot(v, to), 0, {0, 0}});
+    int ret = 0;
+    while (!st.empty()) {
+        Frame &f = st.back();
+        const int idx = (f.v - nt) * 3 + f.k;
+        if (f.stage == 0) {
+            if (G.valid[idx]) { ret = 0; st.pop_back(); continue; }
+            if (G.pend_level[idx] >= 0) { ret = G.pend_level[idx]; st.pop_back(); continue; }
+        }
+        int ch[2], ci = 0;
+        for (int q = 0; q < 3; ++q) if (q != f.k) ch[ci++] = G.tree.nbr[f.v][q];
+        if (f.stage >= 1) f.lv[f.stage - 1] = ret;
+        if (f.stage < 2) {
+            const int c = ch[f.stage];
+            f.stage++;
+            if (c < nt) { ret = 0; continue; }            // tip child: level 0, stay in this frame
+            const int fv = f.v;
+            st.push_back({c, fv, G.tree.slot(c, fv), 0, {0, 0}});
+            continue;
+        }
+        const int lvl = std::max(f.lv[0], f.lv[1]) + 1;
+        PendingOp op; op.gene = g; op.idx = idx; op.level = lvl; ci = 0;
+        for (int q = 0; q < 3; ++q) if (q != f.k) { op.child[ci] = G.tree.nbr[f.v][q]; op.t[ci] = G.tree.len[f.v][q]; ci++; }
+        ops.push_back(op);
+        G.pend_level[idx] = lvl;
+        ret = lvl;
+        st.pop_back();
+    }
+    return ret;
+}
+
+// ------------------------------------------------------------------------------------------
+// run: one upload, pmat, newview levels, tails, one sync
+// ------------------------------------------------------------------------------------------
+int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
+    HIPCHK(hipSetDevice(ctx->device));
+    // group by gene, keeping each gene's dependency order (children are emitted before parents)
+    std::stable_sort(ops.begin(), ops.end(), [](const PendingOp &a, const PendingOp &b) { return a.gene < b.gene; });
+    const size_t nops = ops.size(), ntail = tails.size();
+    size_t neval = 0, nnewton = 0;
+    for (auto &t : tails) { if (t.mode == MODE_EVALUATE) neval++; else nnewton++; }
+    const size_t nreq = 2 * nops + neval;
+    if (int rc = ensure_frags(std::max(nreq, (size_t)1))) return rc;
+    const size_t ngenes = genes.size();
+    const size_t o_req = 0;
+    const size_t o_ops = align_up(o_req + nreq * sizeof(PmatReq), 256);
+    const size_t o_runs = align_up(o_ops + (nops + ntail) * sizeof(NvOp), 256);
+    const size_t o_red = align_up(o_runs + ngenes * sizeof(GeneRun), 256);
+    const size_t o_newt = align_up(o_red + neval * sizeof(ReduceReq), 256);
+    const size_t bytes = align_up(o_newt + nnewton * sizeof(NewtonReq), 256);
+    if (int rc = ensure_stage(bytes)) return rc;
+    char *hs = (char *)h_stage, *ds = (char *)d_stage;
+    PmatReq *hreq = (PmatReq *)(hs + o_req);
+    NvOp *hops = (NvOp *)(hs + o_ops);
+    GeneRun *hruns = (GeneRun *)(hs + o_runs);
+    ReduceReq *hred = (ReduceReq *)(hs + o_red);
+    NewtonReq *hnewt = (NewtonReq *)(hs + o_newt);
+    const double *eig = ctx->d_eigfrags[pi_mode];
+
+    auto side = [&](Gene &G, int node, int toward, const void *&ptr, const int *&scl, bool &tip) {
+        const int nt = G.aln.ntax, mp = G.aln.mpad;
+        if (node < nt) { ptr = G.d_codes + (size_t)node * mp; scl = nullptr; tip = true; return 0; }
+        const int idx = (node - nt) * 3 + G.tree.slot(node, toward);
+        const int s = G.slot_of[idx];
+        if (s < 0) return -1;
+        ptr = G.d_clv + (size_t)s * CLV_ROWS * mp; scl = G.d_scl + (size_t)s * mp; tip = false;
+        return 0;
+    };
+
+    // tails by gene (at most one per gene per run)
+    std::vector<int> tail_of(ngenes, -1);
+    for (size_t i = 0; i < ntail; ++i) {
+        if (tail_of[tails[i].gene] >= 0) return ctx->fail(-1, "internal: two tails for one gene");
+        tail_of[tails[i].gene] = (int)i;
+    }
+    size_t nout = 0, nruns = 0, ie = 0, in = 0, ireq = 0, iop = 0;
+    int max_mpad = 0;
+    double algo_bytes = 0;
+    for (size_t g = 0; g < ngenes; ++g) {
+        const bool has_ops = iop < nops && ops[iop].gene == (int)g;
+        if (!has_ops && tail_of[g] < 0) continue;
+        Gene &G = genes[g];
+        const int nt = G.aln.ntax, mp = G.aln.mpad;
+        GeneRun &run = hruns[nruns++];
+        run.op_begin = (int)nout;
+        max_mpad = std::max(max_mpad, mp);
+        for (; iop < nops && ops[iop].gene == (int)g; ++iop) {
+            PendingOp &o = ops[iop];
+            const int v = nt + o.idx / 3;
+            const int s = slot_for(G, o.idx);
+            if (s < 0) return ctx->fail(-4, "CLV slots exhausted (score-only batch used for a multi-root request)");
+            NvOp &d = hops[nout++];
+            std::memset(&d, 0, sizeof d);
+            d.mode = MODE_NEWVIEW;
+            d.out = G.d_clv + (size_t)s * CLV_ROWS * mp;
+            d.out_scl = G.d_scl + (size_t)s * mp;
+            bool lt, rt;
+            if (side(G, o.child[0], v, d.left, d.l_scl, lt) || side(G, o.child[1], v, d.right, d.r_scl, rt))
+                return ctx->fail(-5, "internal: child message has no slot");
+            d.flags = (lt ? 1 : 0) | (rt ? 2 : 0);
+            d.mpad = mp;
+            d.pl = d_frags + ireq * PFRAG; d.pr = d_frags + (ireq + 1) * PFRAG;
+            for (int c = 0; c < 2; ++c) {
+                PmatReq &r = hreq[ireq++];
+                r.t = o.t[c]; std::memcpy(r.rates, G.rates, sizeof r.rates); r.fold_pi = 0; r.pad = 0;
+            }
+            algo_bytes += (double)G.aln.npat * ((lt ? 1 : 640) + (rt ? 1 : 640) + 640);
+        }
+        if (tail_of[g] >= 0) {
+            const Tail &t = tails[tail_of[g]];
+            NvOp &d = hops[nout++];
+            std::memset(&d, 0, sizeof d);
+            bool lt, rt;
+            if (side(G, t.u, t.v, d.left, d.l_scl, lt) || side(G, t.v, t.u, d.right, d.r_scl, rt))
+                return ctx->fail(-5, "internal: tail message has no slot");
+            d.flags = (lt ? 1 : 0) | (rt ? 2 : 0); d.mpad = mp; d.mode = t.mode;
+            if (t.mode == MODE_EVALUATE) {
+                PmatReq &r = hreq[ireq];
+                r.t = t.t0; std::memcpy(r.rates, G.rates, sizeof r.rates); r.fold_pi = 1; r.pad = 0;
+                d.pl = d.pr = d_frags + ireq * PFRAG; ireq++;
+                d.out = G.d_patlnl; d.out_scl = nullptr;
+                ReduceReq &rr = hred[ie++];
+                rr.patlnl = G.d_patlnl; rr.weight = G.d_weight; rr.out = d_scalars + 8 * g; rr.mpad = mp; rr.pad = 0;
+                algo_bytes += (double)G.aln.npat * ((lt ? 1 : 640) + (rt ? 1 : 640) + 8);
+            } else {
+                d.pl = eig; d.pr = eig + PFRAG;
+                d.out = G.d_sumtab; d.out_scl = G.d_sumscl;
+                NewtonReq &nr = hnewt[in++];
+                nr.sumtab = G.d_sumtab; nr.weight = G.d_weight; nr.scl = G.d_sumscl;
+                std::memcpy(nr.rates, G.rates, sizeof nr.rates);
+                nr.t0 = t.t0; nr.out = d_scalars + 8 * g; nr.mpad = mp; nr.max_iter = t.max_iter;
+                algo_bytes += (double)G.aln.npat * ((lt ? 1 : 640) + (rt ? 1 : 640) + 640);
+            }
+        }
+        run.op_end = (int)nout;
+    }
+
+    HIPCHK(hipMemcpyAsync(ds, hs, bytes, hipMemcpyHostToDevice, ctx->stream));
+    const ModelDev *md = ctx->d_model[pi_mode];
+    if (ireq) {
+        ctx->tic(K_PMAT, (double)ireq * PFRAG * 8);
+        launch_pmat(md, (const PmatReq *)(ds + o_req), d_frags, (int)ireq, ctx->stream);
+        ctx->toc();
+    }
+    if (nruns) {
+        ctx->tic(K_NEWVIEW, algo_bytes);
+        launch_oplist((const NvOp *)(ds + o_ops), (const GeneRun *)(ds + o_runs), (int)nruns, max_mpad, ctx->stream);
+        ctx->toc();
+    }
+    if (neval) {
+        ctx->tic(K_REDUCE, 0);
+        launch_reduce((const ReduceReq *)(ds + o_red), (int)neval, ctx->stream);
+        ctx->toc();
+    }
+    if (nnewton) {
+        double nb = 0;
+        for (auto &t : tails) if (t.mode != MODE_EVALUATE) nb += (double)genes[t.gene].aln.npat * 640;
+        ctx->tic(K_NEWTON, nb);
+        launch_newton(md, (const NewtonReq *)(ds + o_newt), (int)nnewton, ctx->stream);
+        ctx->toc();
+    }
+    if (!tails.empty())
+        HIPCHK(hipMemcpyAsync(h_scalars, d_scalars, sizeof(double) * 8 * genes.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    ctx->resolve_events();
+    for (auto &o : ops) { Gene &G = genes[o.gene]; G.valid[o.idx] = 1; G.pend_level[o.idx] = -1; }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// requests
+// ------------------------------------------------------------------------------------------
+int Batch::evaluate(const std::vector<char> &active, double *lnl) {
+    std::vector<PendingOp> ops; std::vector<Tail> tails;
+    for (int g = 0; g < (int)genes.size(); ++g) {
+        if (!active.empty() && !active[g]) continue;
+        Gene &G = genes[g];
+        const int r = G.tree.nbr[0][0];
+        need(g, r, 0, ops);
+        tails.push_back({g, 0, r, MODE_EVALUATE, G.tree.len[0][0], 0});
+    }
+    if (int rc = run(ops, tails)) return rc;
+    for (auto &t : tails) lnl[t.gene] = h_scalars[8 * t.gene];
+    return 0;
+}
+int Batch::score(const std::vector<char> &active, double *lnl) {
+    for (int g = 0; g < (int)genes.size(); ++g) if (active.empty() || active[g]) invalidate_all(g);
+    return evaluate(active, lnl);
+}
+int Batch::site_lnl(int g, double *out) {
+    Gene &G = genes[g];
+    std::vector<char> act(genes.size(), 0); act[g] = 1;
+    std::vector<double> l(genes.size());
+    if (int rc = evaluate(act, l.data())) return rc;
+    std::vector<double> pat(G.aln.mpad);
+    HIPCHK(hipMemcpy(pat.data(), G.d_patlnl, sizeof(double) * G.aln.mpad, hipMemcpyDeviceToHost));
+    for (int s = 0; s < G.aln.nsites; ++s) out[s] = pat[G.aln.site2pat[s]];
+    return 0;
+}
+int Batch::root_derivs(double *lnl, double *d1, double *d2) {
+    std::vector<PendingOp> ops; std::vector<Tail> tails;
+    for (int g = 0; g < (int)genes.size(); ++g) {
+        Gene &G = genes[g];
+        const int r = G.tree.nbr[0][0];
+        need(g, r, 0, ops);
+        tails.push_back({g, 0, r, MODE_SUMTABLE, G.tree.len[0][0], 0});
+    }
+    if (int rc = run(ops, tails)) return rc;
+    for (int g = 0; g < (int)genes.size(); ++g) { lnl[g] = h_scalars[8 * g + 1]; d1[g] = h_scalars[8 * g + 2]; d2[g] = h_scalars[8 * g + 3]; }
+    return 0;
+}
+
+// one Gauss-Seidel pass over all branches (DFS from taxon 0, oracle order: eng_smooth_rec)
+int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &maxdelta) {
+    const int n = (int)genes.size();
+    maxdelta.assign(n, 0.0);
+    // per-gene DFS edge order
+    std::vector<std::vector<std::pair<int, int>>> order(n);
+    size_t maxlen = 0;
+    for (int g = 0; g < n; ++g) {
+        if (!active[g]) continue;
+        const Tree &T = genes[g].tree; const int nt = T.ntax;
+        // emulate the recursion: visit(v, from): for k: edge (v,w); if inner recurse
+        // (edge list fixed up-front: topology does not change during a pass)
+        struct F { int v, from, k; };
+        std::vector<F> st{{0, -1, 0}};
+        while (!st.empty()) {
+            F &f = st.back();
+            if (f.k >= 3) { st.pop_back(); continue; }
+            const int w = T.nbr[f.v][f.k]; f.k++;
+            if (w < 0 || w == f.from) continue;
+            order[g].push_back({f.v, w});
+            if (w >= nt) { const int fv = f.v; st.push_back({w, fv, 0}); }
+        }
+        maxlen = std::max(maxlen, order[g].size());
+    }
+    for (size_t step = 0; step < maxlen; ++step) {
+        std::vector<PendingOp> ops; std::vector<Tail> tails;
+        for (int g = 0; g < n; ++g) {
+            if (!active[g] || step >= order[g].size()) continue;
+            auto [v, w] = order[g][step];
+            need(g, v, w, ops); need(g, w, v, ops);
+            tails.push_back({g, v, w, MODE_SUMTABLE, genes[g].tree.len[v][genes[g].tree.slot(v, w)], 32});
+        }
+        if (int rc = run(ops, tails)) return rc;
+        for (auto &t : tails) {
+            Gene &G = genes[t.gene];
+            const double nl = h_scalars[8 * t.gene], old = t.t0;
+            maxdelta[t.gene] = std::max(maxdelta[t.gene], std::fabs(nl - old));
+            if (nl != old) { G.tree.set_len(t.u, t.v, nl); branch_changed(t.gene, t.u, t.v); }
+        }
+    }
+    return 0;
+}
+
+int Batch::opt_alpha(const std::vector<char> &active, double *lnl) {
+    const int n = (int)genes.size();
+    std::vector<Brent> br(n);
+    std::vector<char> act(active);
+    std::vector<double> f(n);
+    if (int rc = score(act, f.data())) return rc;
+    for (int g = 0; g < n; ++g) if (act[g]) br[g].start(std::log(ALPHA_MIN), std::log(ALPHA_MAX), std::log(genes[g].alpha), -f[g]);
+    for (;;) {
+        bool any = false;
+        for (int g = 0; g < n; ++g) {
+            if (!act[g]) continue;
+            if (br[g].propose()) { set_alpha(g, std::exp(br[g].u)); any = true; }
+            else act[g] = 0;
+        }
+        if (!any) break;
+        if (int rc = score(act, f.data())) return rc;
+        for (int g = 0; g < n; ++g) if (act[g]) br[g].update(-f[g]);
+    }
+    for (int g = 0; g < n; ++g) if (active[g]) { set_alpha(g, std::exp(br[g].x)); lnl[g] = -br[g].fx; }
+    return 0;
+}
+
+int Batch::optimize(bool opt_alpha_flag, double eps, double *lnl) {
+    const int n = (int)genes.size();
+    for (int g = 0; g < n; ++g) {
+        Tree &T = genes[g].tree;
+        for (auto &l : T.len) for (double &x : l) if (x < TMIN) x = TMIN;
+        invalidate_all(g);
+    }
+    std::vector<char> active(n, 1);
+    std::vector<double> cur(n), nl(n), md;
+    if (int rc = evaluate(active, cur.data())) return rc;
+    for (int round = 0; round < 100; ++round) {
+        bool any = false; for (char a : active) any |= a;
+        if (!any) break;
+        std::vector<char> sm(active);
+        for (int pass = 0; pass < 16; ++pass) {
+            bool anys = false; for (char a : sm) anys |= a;
+            if (!anys) break;
+            if (int rc = smooth_pass(sm, md)) return rc;
+            for (int g = 0; g < n; ++g) if (sm[g] && md[g] < 1e-6) sm[g] = 0;
+        }
+        if (opt_alpha_flag) { if (int rc = opt_alpha(active, nl.data())) return rc; }
+        else { if (int rc = evaluate(active, nl.data())) return rc; }
+        for (int g = 0; g < n; ++g) {
+            if (!active[g]) continue;
+            const double gain = nl[g] - cur[g]; cur[g] = nl[g];
+            if (gain < eps) active[g] = 0;
+        }
+    }
+    for (int g = 0; g < n; ++g) lnl[g] = cur[g];
+    return 0;
+}
+
+}  // namespace pml

@@ -1,0 +1,102 @@
+// engine.hpp -- device-resident gene batches and the host-side schedulers that drive the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "host.hpp"
+#include "kernels.h"
+
+namespace pml {
+
+enum { K_PMAT = 0, K_NEWVIEW = 1, K_EVALUATE = 2, K_SUMTABLE = 3, K_NEWTON = 4, K_REDUCE = 5, K_COUNT = 6 };
+
+struct Ctx {
+    int device = 0;
+    bool profile = false;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string last_error;
+    Model model[2];
+    bool model_ready[2] = {false, false};
+    ModelDev *d_model[2] = {nullptr, nullptr};
+    double *d_eigfrags[2] = {nullptr, nullptr};   // 2*PFRAG doubles each
+    struct KStat { long long launches = 0; double ms = 0; double bytes = 0; } stats[K_COUNT];
+    struct Ev { int kind; hipEvent_t a, b; };
+    std::vector<Ev> pending;
+    std::vector<hipEvent_t> pool;
+
+    int init(int dev, bool prof);
+    void destroy();
+    int ensure_model(int pi_mode);
+    hipEvent_t get_event();
+    void tic(int kind, double bytes);   // record start (profile mode)
+    void toc();                          // record stop
+    void resolve_events();               // after a stream sync
+    int fail(int code, const std::string &msg) { last_error = msg; return code; }
+};
+
+struct Gene {
+    EncodedAlignment aln;
+    Tree tree;
+    double alpha = 1.0;
+    double rates[NCAT] = {1, 1, 1, 1};
+    // device pointers (inside the batch arena)
+    uint8_t *d_codes = nullptr;
+    double *d_weight = nullptr;
+    double *d_clv = nullptr;       // slot_cap slots of 80*mpad doubles
+    int *d_scl = nullptr;          // slot_cap slots of mpad ints
+    double *d_sumtab = nullptr;    // 80*mpad
+    int *d_sumscl = nullptr;       // mpad
+    double *d_patlnl = nullptr;    // mpad
+    int slot_cap = 0, next_slot = 0;
+    std::vector<int> slot_of;      // directed-edge index (v-ntax)*3+k -> slot (-1 = none)
+    std::vector<uint8_t> valid;
+    std::vector<int> pend_level;   // scratch for collection (-1 = not pending)
+};
+
+struct pml_alignment_view { int ntax, nsites; const char *const *names; const char *const *rows; };
+
+struct PendingOp { int gene, idx, level; int child[2]; double t[2]; };
+
+struct Batch {
+    Ctx *ctx = nullptr;
+    int pi_mode = 0, ncat = 4;
+    std::vector<Gene> genes;
+    char *arena = nullptr; size_t arena_bytes = 0;
+    // staging (pinned host mirrors + device buffers), grown on demand
+    void *h_stage = nullptr; size_t h_cap = 0;
+    void *d_stage = nullptr; size_t d_cap = 0;
+    double *d_frags = nullptr; size_t frag_cap = 0;      // in fragment sets
+    double *d_scalars = nullptr; double *h_scalars = nullptr;   // 8 doubles per gene
+
+    int create(Ctx *c, int n, const pml_alignment_view *alns, const char *const *newicks,
+               int pi_mode, int ncat, double alpha, bool score_only);
+    void destroy();
+
+    void set_alpha(int g, double alpha);
+    void invalidate_all(int g);
+    void branch_changed(int g, int a, int b);
+    // lnL of every active gene at the branch above taxon 0, using/refreshing cached CLVs
+    int evaluate(const std::vector<char> &active, double *lnl);
+    int score(const std::vector<char> &active, double *lnl);      // invalidate + evaluate
+    int site_lnl(int g, double *out);
+    int root_derivs(double *lnl, double *d1, double *d2);
+    int smooth_pass(const std::vector<char> &active, std::vector<double> &maxdelta);
+    int opt_alpha(const std::vector<char> &active, double *lnl);
+    int optimize(bool opt_alpha_flag, double eps, double *lnl);
+    int search(bool nni, int spr_radius, bool opt_alpha_flag, double eps, double *lnl);
+
+    // --- plumbing ---
+    int need(int g, int v, int to, std::vector<PendingOp> &ops);   // returns level
+    // run the collected newviews, then the tail ops (evaluate or sumtable+newton), one sync
+    struct Tail { int gene, u, v; int mode; double t0; int max_iter; };
+    int run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails);
+    int ensure_stage(size_t bytes);
+    int ensure_frags(size_t sets);
+    int slot_for(Gene &g, int idx);
+};
+
+}  // namespace pml

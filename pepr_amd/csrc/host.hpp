@@ -1,0 +1,67 @@
+// host.hpp -- host-side model / alignment / tree types of libpeprml (no device code here).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace pml {
+
+constexpr double TMIN = 1.0e-6;     // RAxML 7.2.5 zmax = 1 - 1e-6
+constexpr double TMAX = 34.5;       // RAxML 7.2.5 zmin = 1e-15
+constexpr double ALPHA_MIN = 0.02;
+constexpr double ALPHA_MAX = 1000.0;
+
+struct Model {
+    double pi[20];
+    double Q[400];
+    double eval[20];
+    double U[400];      // P(t) = U diag(exp(eval t)) Uinv
+    double Uinv[400];
+    void init(int pi_mode);
+};
+
+// mean rates of K equal-probability Gamma(alpha, mean 1) bins (Yang 1994); K==1 -> {1}
+void gamma_rates(double alpha, int K, double *rates);
+
+int aa_code(int ch);                 // 0..19, 20 = B, 21 = Z, 22 = gap/unknown
+
+struct Tree {
+    int ntax = 0;
+    std::vector<std::array<int, 3>> nbr;       // -1 = unused (tips use slot 0 only)
+    std::vector<std::array<double, 3>> len;
+    int nnodes() const { return (int)nbr.size(); }
+    int slot(int v, int w) const { for (int k = 0; k < 3; ++k) if (nbr[v][k] == w) return k; return -1; }
+    void set_len(int u, int v, double l) { len[u][slot(u, v)] = l; len[v][slot(v, u)] = l; }
+    double length() const;
+    // names[i] is the label of tip i; returns false and fills err on failure
+    static bool parse(const char *newick, const std::vector<std::string> &names, Tree &out, std::string &err);
+    // parse without an alignment: tips numbered in order of appearance, names returned
+    static bool parse_free(const char *newick, std::vector<std::string> &names, Tree &out, std::string &err);
+    std::string newick(const std::vector<std::string> &names, int digits) const;
+};
+
+int rf_distance(const Tree &a, const Tree &b);    // (|A|+|B|-2|A&B|)/2 over non-trivial splits
+
+struct EncodedAlignment {
+    int ntax = 0, nsites = 0, npat = 0, mpad = 0;
+    std::vector<std::string> names;
+    std::vector<uint8_t> codes;     // [ntax][mpad], padding = gap code
+    std::vector<double> weight;     // [mpad], padding = 0
+    std::vector<int> site2pat;      // [nsites]
+    // rows: ntax pointers to nsites chars; identical columns are merged (first-occurrence order)
+    bool encode(int ntax, int nsites, const char *const *names, const char *const *rows, std::string &err);
+};
+
+Tree nj_tree(const EncodedAlignment &a);
+
+// resumable Brent minimiser on a fixed interval (same control flow as the oracle's eng_opt_alpha)
+struct Brent {
+    double a, b, x, w, v, fx, fw, fv, d, e, u;
+    int iter; bool done;
+    void start(double lo, double hi, double x0, double fx0);
+    bool propose();            // sets u; returns false when converged
+    void update(double fu);
+};
+
+}  // namespace pml

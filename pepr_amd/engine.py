@@ -1,0 +1,194 @@
+"""Thin Python view of the C ABI (include/peprml.h): Context, resident Batch, one-shot calls.
+
+PyTorch is not needed here; it is used only by bench.py / distributed.py for rank plumbing.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+KERNELS = {"pmat": 0, "newview": 1, "evaluate": 2, "sumtable": 3, "newton": 4, "reduce": 5}
+PI_RAXML_3DP, PI_WAG_FULL = 0, 1
+
+
+class PmlError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        msg = _lib.load().pml_strerror(code).decode()
+        super().__init__("%s (%d)%s" % (msg, code, ": " + detail if detail else ""))
+
+
+def _aln_struct(names, rows, keep):
+    n = len(names)
+    if n != len(rows):
+        raise ValueError("names/rows length mismatch")
+    L = len(rows[0]) if n else 0
+    for r in rows:
+        if len(r) != L:
+            raise ValueError("alignment rows have different lengths")
+    na = (C.c_char_p * n)(*[s.encode() if isinstance(s, str) else s for s in names])
+    ra = (C.c_char_p * n)(*[s.encode() if isinstance(s, str) else s for s in rows])
+    keep.extend([na, ra])
+    return _lib.Alignment(n, L, na, ra)
+
+
+def _model(ncat=4, alpha=1.0, pi_mode=PI_RAXML_3DP):
+    return _lib.Model(ncat, alpha, pi_mode)
+
+
+def _opts(optimize_alpha=True, nni=True, spr_radius=0, epsilon=0.0, seed=0):
+    return _lib.SearchOpts(int(optimize_alpha), int(nni), int(spr_radius), float(epsilon), int(seed))
+
+
+class Context:
+    """One engine context = one HIP device + stream (one per rank / per GPU)."""
+
+    def __init__(self, device=0, profile=False):
+        self.L = _lib.load()
+        self.ptr = C.c_void_p()
+        cfg = _lib.Config(device, int(profile), 0)
+        rc = self.L.pml_create(C.byref(cfg), C.byref(self.ptr))
+        if rc:
+            raise PmlError(rc, self.L.pml_last_error(None).decode())
+
+    def _check(self, rc):
+        if rc:
+            raise PmlError(rc, self.L.pml_last_error(self.ptr).decode())
+
+    def close(self):
+        if self.ptr:
+            self.L.pml_destroy(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- one-shot, gene-batched ----
+    def _oneshot(self, fn, genes, newicks, model, extra):
+        keep = []
+        n = len(genes)
+        alns = (_lib.Alignment * n)(*[_aln_struct(g[0], g[1], keep) for g in genes])
+        nw = None
+        if newicks is not None:
+            nw = (C.c_char_p * n)(*[(s.encode() if s is not None else None) for s in newicks])
+        res = (_lib.Result * n)()
+        rc = fn(self.ptr, n, alns, nw, C.byref(model), *extra, res)
+        out = []
+        if rc == 0:
+            for r in res:
+                d = {"lnl": r.lnl, "alpha": r.alpha, "tree_length": r.tree_length, "npatterns": r.npatterns,
+                     "nsites": r.nsites, "newick": C.string_at(r.newick).decode() if r.newick else None}
+                if r.site_lnl:
+                    d["site_lnl"] = np.ctypeslib.as_array(r.site_lnl, shape=(max(r.nsites, 1),))[:r.nsites].copy()
+                out.append(d)
+        for r in res:
+            self.L.pml_result_free(C.byref(r))
+        self._check(rc)
+        return out
+
+    def score(self, genes, newicks, alpha=1.0, ncat=4, pi_mode=PI_RAXML_3DP, site_lnl=False):
+        """genes: list of (names, rows); newicks: list of str.  Fixed tree + lengths + alpha -> lnL."""
+        return self._oneshot(self.L.pml_score_batch, genes, newicks, _model(ncat, alpha, pi_mode), (1 if site_lnl else 0,))
+
+    def optimize(self, genes, newicks, alpha=1.0, ncat=4, pi_mode=PI_RAXML_3DP, optimize_alpha=True, epsilon=1e-4):
+        o = _opts(optimize_alpha, False, 0, epsilon)
+        return self._oneshot(self.L.pml_optimize_batch, genes, newicks, _model(ncat, alpha, pi_mode), (C.byref(o),))
+
+    def search(self, genes, start_newicks=None, alpha=1.0, ncat=4, pi_mode=PI_RAXML_3DP, optimize_alpha=True,
+               nni=True, spr_radius=0, epsilon=1e-3):
+        o = _opts(optimize_alpha, nni, spr_radius, epsilon)
+        return self._oneshot(self.L.pml_search_batch, genes, start_newicks, _model(ncat, alpha, pi_mode), (C.byref(o),))
+
+    def kernel_stats(self, reset=False):
+        out = {}
+        for name, k in KERNELS.items():
+            n, ms, by = C.c_longlong(), C.c_double(), C.c_double()
+            self._check(self.L.pml_kernel_stats(self.ptr, k, C.byref(n), C.byref(ms), C.byref(by)))
+            out[name] = {"launches": n.value, "ms": ms.value, "algo_bytes": by.value}
+        if reset:
+            self.L.pml_kernel_stats_reset(self.ptr)
+        return out
+
+
+class Batch:
+    """Genes encoded and resident in HBM; repeated evaluation without host transfers."""
+
+    def __init__(self, ctx, genes, newicks=None, alpha=1.0, ncat=4, pi_mode=PI_RAXML_3DP):
+        self.ctx, self.L = ctx, ctx.L
+        keep = []
+        n = len(genes)
+        alns = (_lib.Alignment * n)(*[_aln_struct(g[0], g[1], keep) for g in genes])
+        nw = None
+        if newicks is not None:
+            nw = (C.c_char_p * n)(*[(s.encode() if s is not None else None) for s in newicks])
+        m = _model(ncat, alpha, pi_mode)
+        self.ptr = C.c_void_p()
+        ctx._check(self.L.pml_batch_create(ctx.ptr, n, alns, nw, C.byref(m), C.byref(self.ptr)))
+        self.n = n
+
+    def close(self):
+        if self.ptr:
+            self.L.pml_batch_destroy(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def npatterns(self):
+        return [self.L.pml_batch_npatterns(self.ptr, g) for g in range(self.n)]
+
+    def score(self):
+        out = np.zeros(self.n)
+        self.ctx._check(self.L.pml_batch_score(self.ptr, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def site_lnl(self, g, nsites):
+        out = np.zeros(max(nsites, 1))
+        self.ctx._check(self.L.pml_batch_site_lnl(self.ptr, g, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out[:nsites]
+
+    def set_alpha(self, alpha, g=-1):
+        self.ctx._check(self.L.pml_batch_set_alpha(self.ptr, g, alpha))
+
+    def root_derivs(self):
+        a, b, c = np.zeros(self.n), np.zeros(self.n), np.zeros(self.n)
+        dp = C.POINTER(C.c_double)
+        self.ctx._check(self.L.pml_batch_root_derivs(self.ptr, a.ctypes.data_as(dp), b.ctypes.data_as(dp), c.ctypes.data_as(dp)))
+        return a, b, c
+
+    def optimize(self, optimize_alpha=True, epsilon=1e-4):
+        o = _opts(optimize_alpha, False, 0, epsilon)
+        lnl, al = np.zeros(self.n), np.zeros(self.n)
+        dp = C.POINTER(C.c_double)
+        self.ctx._check(self.L.pml_batch_optimize(self.ptr, C.byref(o), lnl.ctypes.data_as(dp), al.ctypes.data_as(dp)))
+        return lnl, al
+
+    def search(self, optimize_alpha=True, nni=True, spr_radius=0, epsilon=1e-3):
+        o = _opts(optimize_alpha, nni, spr_radius, epsilon)
+        lnl, al = np.zeros(self.n), np.zeros(self.n)
+        dp = C.POINTER(C.c_double)
+        self.ctx._check(self.L.pml_batch_search(self.ptr, C.byref(o), lnl.ctypes.data_as(dp), al.ctypes.data_as(dp)))
+        return lnl, al
+
+    def newick(self, g, digits=10):
+        p = C.c_void_p()
+        self.ctx._check(self.L.pml_batch_newick(self.ptr, g, digits, C.byref(p)))
+        s = C.string_at(p).decode()
+        self.L.pml_free(p)
+        return s
+
+
+def rf_distance(newick_a, newick_b):
+    L = _lib.load()
+    rf = C.c_int()
+    rc = L.pml_rf_distance(newick_a.encode(), newick_b.encode(), C.byref(rf))
+    if rc:
+        raise PmlError(rc, L.pml_last_error(None).decode())
+    return rf.value
