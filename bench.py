@@ -1,0 +1,132 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric on synthetic data.
+
+Step = one full pass of the hot path over one batch: for every gene, transition matrices for all
+branches, the complete post-order CLV pass (newview), root evaluation and the weighted lnL
+reduction -- inputs (encoded alignments, trees) already resident in HBM.
+
+Workload (weak scaling, genes sharded over ranks, no data-path collective):
+  c3 (default): BASELINE config[2], 128 genes x (50 taxa x 1000 AA sites) per GPU, WAG+G4, f64
+  c4:           BASELINE config[3] shard, 63 genes x (200 x 5000) per GPU (500 genes / 8 GPUs)
+`value` = M site-lnL/s = 1e-6 x alignment patterns x full-tree likelihood evaluations per second,
+summed over all ranks.  Launch: python bench.py --gpus N --steps K --warmup W  (N>1 through
+torch.distributed.run, one rank per GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def cpu_baseline(genes, alpha, budget_s=12.0):
+    """Oracle (single-thread C port) on a bounded sample of the same workload."""
+    from oracle import po
+    m = po.Model(0)
+    objs = []
+    for names, rows, nw in genes:
+        a = po.Alignment(names, rows); t = po.Tree(nw, a); e = po.Engine(a, m, 4, alpha)
+        objs.append((a, t, e))
+    npat = sum(o[0].npat for o in objs)
+    reps, t0 = 0, time.time()
+    while True:
+        for a, t, e in objs:
+            e.set_alpha(alpha)          # invalidates every CLV: a full traversal, as on the GPU
+            e.lnl(t)
+        reps += 1
+        if time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    return {"value": npat * reps / dt / 1e6, "unit": "M site-lnL/s", "cores": 1, "kind": "port",
+            "sample": "%d genes of the workload x %d full-tree evaluations, %.1f s, oracle/pml_oracle.c (gcc -O2, 1 thread)" % (len(objs), reps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "tiny"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from pepr_amd import distributed as pd, engine, synth
+
+    rank, local, world = pd.init_from_env()
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    torch.cuda.set_device(local)
+
+    ntax, nsites, per_gpu = {"c3": (50, 1000, 128), "c4": (200, 5000, 63), "tiny": (12, 200, 8)}[args.workload]
+    alpha = 0.8
+    gene_ids = [rank * per_gpu + i for i in range(per_gpu)]            # contiguous shard of the global list
+    genes = [synth.simulate_alignment(ntax, nsites, 1 + gid, alpha) for gid in gene_ids]
+    ctx = engine.Context(local, profile=True)
+    batch = engine.Batch(ctx, [(g[0], g[1]) for g in genes], [g[2] for g in genes], alpha=alpha)
+    npat = sum(batch.npatterns())
+
+    def step():
+        lnl = batch.score()
+        if world > 1:                      # the one gather of per-gene results (RCCL over xGMI)
+            pd.gather_results(gene_ids, lnl)
+        return lnl
+
+    for _ in range(args.warmup):
+        lnl = step()
+    ctx.kernel_stats(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lnl = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    stats = ctx.kernel_stats()
+    assert np.all(np.isfinite(lnl))
+
+    tot_pat = npat
+    if world > 1:
+        t = torch.tensor([dt, float(npat)], dtype=torch.float64, device="cuda")
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, tot_pat = float(tmax[0]), float(tsum[1])
+
+    if rank == 0:
+        nv = stats["newview"]
+        avg_ms = nv["ms"] / max(nv["launches"], 1)
+        achieved = nv["algo_bytes"] / max(nv["launches"], 1) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "M site-lnL/sec (WAG+G4 full-tree likelihood evaluations x alignment patterns)",
+            "value": tot_pat * args.steps / dt / 1e6, "unit": "M site-lnL/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %d genes/GPU x %d taxa x %d AA sites, WAG+G4 (RAxML PROTGAMMAWAG conventions), seeds 1..G" % (
+                args.workload, per_gpu, ntax, nsites), "patterns_per_gpu": npat, "genes_total": per_gpu * world,
+                "parallelism": "gene-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_oplist (newview+evaluate)", "achieved": achieved, "peak": 8000.0,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "avg_launch_ms": avg_ms, "algo_bytes_per_launch": nv["algo_bytes"] / max(nv["launches"], 1)},
+            "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in stats.items() if v["launches"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(genes[:2], alpha)
+        print(json.dumps(out), flush=True)
+    batch.close(); ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    from oracle import po
+    po.build()
+    return po
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    from pepr_amd import engine
+    ctx = engine.Context(0, profile=False)
+    yield ctx
+    ctx.close()

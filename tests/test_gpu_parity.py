@@ -1,0 +1,192 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP engine, called through the C ABI
+(include/peprml.h via ctypes), against the CPU oracle and the committed golden fixtures.
+
+Tolerances: likelihoods are float64 on both sides; the only differences are summation order and
+FMA contraction, so per-site lnL must agree to 1e-9 and totals to 1e-9 relative -- three orders
+tighter than the north star's |dlnL| < 1e-3 per gene."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from pepr_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "scoring_cases.json")
+REL = 1e-9
+
+
+def _oracle(po, names, rows, nw, alpha, pi_mode=0):
+    a = po.Alignment(names, rows); t = po.Tree(nw, a); e = po.Engine(a, po.Model(pi_mode), 4, alpha)
+    return a, t, e
+
+
+def test_golden_fixtures(gpu_ctx):
+    cases = json.load(open(GOLD))["cases"]
+    for pm in (0, 1):
+        sel = [c for c in cases if c["pi_mode"] == pm]
+        for c in sel:      # alpha differs per case -> one call each (alpha is per call)
+            r = gpu_ctx.score([(c["names"], c["rows"])], [c["newick"]], alpha=c["alpha"], pi_mode=pm, site_lnl=True)[0]
+            assert r["npatterns"] == c["npat"]
+            assert abs(r["lnl"] - c["lnl"]) < REL * max(1.0, abs(c["lnl"]))
+            assert np.abs(r["site_lnl"] - np.array(c["site_lnl"])).max() < 1e-8
+
+
+@pytest.mark.parametrize("ntax,nsites,seed,alpha,miss", [
+    (3, 17, 1, 1.0, 0.0), (4, 60, 3, 0.7, 0.0), (8, 300, 5, 2.5, 0.0), (12, 2000, 7, 0.8, 0.3),
+    (50, 1000, 1, 0.8, 0.0), (33, 31, 2, 0.05, 0.5), (6, 1, 9, 1.0, 0.0), (64, 129, 4, 50.0, 0.1)])
+def test_score_vs_oracle(gpu_ctx, oracle_lib, ntax, nsites, seed, alpha, miss):
+    names, rows, nw = synth.simulate_alignment(ntax, nsites, seed, missing_frac=miss)
+    a, t, e = _oracle(oracle_lib, names, rows, nw, alpha)
+    ref, refs = e.site_lnl(t)
+    r = gpu_ctx.score([(names, rows)], [nw], alpha=alpha, site_lnl=True)[0]
+    assert r["npatterns"] == a.npat and r["nsites"] == nsites
+    assert abs(r["lnl"] - ref) < REL * max(1.0, abs(ref))
+    assert np.abs(r["site_lnl"] - refs).max() < 1e-9 * max(1.0, np.abs(refs).max())
+    assert abs(r["tree_length"] - t.length()) < 1e-12 * max(1.0, t.length())
+
+
+def test_ragged_batch(gpu_ctx, oracle_lib):
+    """Genes of different taxon counts / lengths in ONE batch (gene-wise jackknife subsets differ)."""
+    shapes = [(5, 40), (17, 333), (9, 1), (40, 700), (3, 64), (26, 95)]
+    genes, nws, refs = [], [], []
+    for i, (nt, ns) in enumerate(shapes):
+        names, rows, nw = synth.simulate_alignment(nt, ns, 100 + i, missing_frac=0.15 * (i % 2))
+        genes.append((names, rows)); nws.append(nw)
+        a, t, e = _oracle(oracle_lib, names, rows, nw, 0.65)
+        refs.append(e.lnl(t))
+    out = gpu_ctx.score(genes, nws, alpha=0.65)
+    for r, ref in zip(out, refs):
+        assert abs(r["lnl"] - ref) < REL * max(1.0, abs(ref))
+
+
+def test_ambiguity_gap_and_case(gpu_ctx, oracle_lib):
+    names = ["a", "b", "c", "d", "e"]
+    rows = ["ARNDCQEGHILKMFPSTWYV-?XBZJUO*.arndc", "ARNDCQEGHILKMFPSTWYVAAAAAAAAAAarndc",
+            "-------------------------------ARND", "BZBZBZBZBZXXXXXXXXXX???????????KKKK", "VYWTSPFMKLIHGEQCDNRA-?XBZJUO*.vywts"]
+    nw = "((a:0.3,b:0.1):0.05,c:0.7,(d:1.2,e:0.01):0.2);"
+    a, t, e = _oracle(oracle_lib, names, rows, nw, 0.4)
+    ref, refs = e.site_lnl(t)
+    r = gpu_ctx.score([(names, rows)], [nw], alpha=0.4, site_lnl=True)[0]
+    assert abs(r["lnl"] - ref) < REL * abs(ref) and np.abs(r["site_lnl"] - refs).max() < 1e-10
+
+
+def test_underflow_rescue_on_device(gpu_ctx, oracle_lib):
+    """Deep caterpillar with long branches: the 2^256 rescue path of the kernel."""
+    n, L = 400, 40
+    rng = np.random.default_rng(5)
+    names = ["s%d" % i for i in range(n)]
+    rows = ["".join(rng.choice(list(synth.AA), L)) for _ in range(n)]
+    nw = names[0]
+    for i in range(1, n):
+        nw = "(%s:0.9,%s:1.3)" % (nw, names[i])
+    nw += ";"
+    a, t, e = _oracle(oracle_lib, names, rows, nw, 0.9)
+    ref, refs = e.site_lnl(t)
+    assert refs.min() < -800
+    r = gpu_ctx.score([(names, rows)], [nw], alpha=0.9, site_lnl=True)[0]
+    assert abs(r["lnl"] - ref) < REL * abs(ref) and np.abs(r["site_lnl"] - refs).max() < 1e-8
+
+
+def test_zero_and_huge_branches(gpu_ctx, oracle_lib):
+    names, rows, _ = synth.simulate_alignment(6, 50, 77)
+    rows[1] = rows[0]      # zero-length cherry: only meaningful for identical sequences
+    nw = "((t0:0.0,t1:0.0):0.0,(t2:40.0,t3:1e-9):2.0,(t4:0.5,t5:0.25):0.0);"
+    a, t, e = _oracle(oracle_lib, names, rows, nw, 1.0)
+    ref = e.lnl(t)
+    r = gpu_ctx.score([(names, rows)], [nw], alpha=1.0)[0]
+    assert np.isfinite(ref) and abs(r["lnl"] - ref) < REL * abs(ref)
+
+
+def test_ncat1_and_full_pi(gpu_ctx, oracle_lib):
+    po = oracle_lib
+    names, rows, nw = synth.simulate_alignment(10, 120, 55)
+    a = po.Alignment(names, rows); t = po.Tree(nw, a)
+    ref1 = po.Engine(a, po.Model(1), 1, 1.0).lnl(t)
+    r1 = gpu_ctx.score([(names, rows)], [nw], alpha=1.0, ncat=1, pi_mode=1)[0]
+    assert abs(r1["lnl"] - ref1) < REL * abs(ref1)
+
+
+def test_errors_through_abi(gpu_ctx):
+    from pepr_amd import engine
+    names, rows, nw = synth.simulate_alignment(5, 20, 1)
+    with pytest.raises(engine.PmlError) as ei:
+        gpu_ctx.score([(names, rows)], ["(t0:1,(t1:1,t2:1):1,(t3:1,nope:1):1);"])
+    assert ei.value.code == -2 and "nope" in str(ei.value)
+    with pytest.raises(engine.PmlError):
+        gpu_ctx.score([(names[:2], rows[:2])], ["(t0:1,t1:1);"])
+    with pytest.raises(engine.PmlError):
+        gpu_ctx.score([(names, rows)], [nw], ncat=3)
+    # the context stays usable after an error
+    assert np.isfinite(gpu_ctx.score([(names, rows)], [nw])[0]["lnl"])
+
+
+def test_root_derivatives_vs_oracle(gpu_ctx, oracle_lib):
+    from pepr_amd import engine
+    import ctypes as C
+    genes, nws, refs = [], [], []
+    for i, (nt, ns) in enumerate([(7, 90), (20, 400), (4, 33)]):
+        names, rows, nw = synth.simulate_alignment(nt, ns, 200 + i, missing_frac=0.1)
+        genes.append((names, rows)); nws.append(nw)
+        a, t, e = _oracle(oracle_lib, names, rows, nw, 0.6)
+        class TS(C.Structure):
+            _fields_ = [("ntax", C.c_int), ("nnodes", C.c_int), ("nbr", C.POINTER(C.c_int * 3)), ("len", C.POINTER(C.c_double * 3))]
+        ts = C.cast(t.ptr, C.POINTER(TS)).contents
+        refs.append(e.branch_derivs(t, 0, ts.nbr[0][0]))
+    b = engine.Batch(gpu_ctx, genes, nws, alpha=0.6)
+    l, d1, d2 = b.root_derivs()
+    for g, (rl, r1, r2) in enumerate(refs):
+        assert abs(l[g] - rl) < REL * abs(rl)
+        assert abs(d1[g] - r1) < 1e-8 * max(1.0, abs(r1)) and abs(d2[g] - r2) < 1e-8 * max(1.0, abs(r2))
+    b.close()
+
+
+def test_optimize_vs_oracle(gpu_ctx, oracle_lib):
+    """-f e analogue (FastTreeRunner.java:142-199): same Newton/Brent control flow on both sides;
+    north-star tolerance |dlnL| < 1e-3, alpha to 1e-4."""
+    genes, nws, refs = [], [], []
+    for i, (nt, ns) in enumerate([(12, 500), (8, 300), (25, 250)]):
+        names, rows, nw = synth.simulate_alignment(nt, ns, 300 + i, missing_frac=0.1 * (i == 2))
+        genes.append((names, rows)); nws.append(nw)
+        a, t, e = _oracle(oracle_lib, names, rows, nw, 1.0)
+        lnl = e.optimize(t, True, 1e-4)
+        refs.append((lnl, e.alpha, t.length()))
+    out = gpu_ctx.optimize(genes, nws, alpha=1.0, epsilon=1e-4)
+    for r, (lnl, al, tl) in zip(out, refs):
+        assert abs(r["lnl"] - lnl) < 1e-3
+        assert abs(r["alpha"] - al) < 1e-4 * max(1.0, al) and abs(r["tree_length"] - tl) < 1e-4 * tl
+        # the returned tree + alpha reproduce the returned lnL when scored from scratch
+        g = genes[out.index(r)]
+        again = gpu_ctx.score([g], [r["newick"]], alpha=r["alpha"])[0]["lnl"]
+        assert abs(again - r["lnl"]) < 1e-6
+
+
+def test_golden_optimize(gpu_ctx):
+    cases = json.load(open(GOLD))["cases"]
+    for c in cases:
+        if len(c["names"]) < 4 or len(c["rows"][0]) < 30:
+            continue
+        r = gpu_ctx.optimize([(c["names"], c["rows"])], [c["newick"]], alpha=c["alpha"], pi_mode=c["pi_mode"], epsilon=1e-4)[0]
+        assert abs(r["lnl"] - c["opt_lnl"]) < 1e-3, (r["lnl"], c["opt_lnl"])
+
+
+def test_full_size_properties_c3(gpu_ctx):
+    """BASELINE config C3 (50 taxa x 1000 sites x 128 genes) at full size: properties that need no
+    oracle -- re-rooting invariance (pulley principle), sum of per-site = total, column duplication
+    doubles lnL, resident batch == one-shot, determinism."""
+    from pepr_amd import engine
+    genes = synth.simulate_genes(128, 50, 1000)
+    G = [(g[0], g[1]) for g in genes]; NW = [g[2] for g in genes]
+    b = engine.Batch(gpu_ctx, G, NW, alpha=0.8)
+    l1 = b.score(); l2 = b.score()
+    assert np.array_equal(l1, l2) and np.all(np.isfinite(l1)) and np.all(l1 < 0)
+    s0 = b.site_lnl(0, 1000)
+    assert abs(s0.sum() - l1[0]) < 1e-8 * abs(l1[0])
+    rer = [b.newick(g, 17) for g in range(4)]          # unrooted re-serialisation at taxon 0
+    b.close()
+    out = gpu_ctx.score(G[:4], rer, alpha=0.8)
+    for g in range(4):
+        assert abs(out[g]["lnl"] - l1[g]) < 1e-8 * abs(l1[g])
+    dup = [(G[0][0], [r + r for r in G[0][1]])]
+    assert abs(gpu_ctx.score(dup, NW[:1], alpha=0.8)[0]["lnl"] - 2 * l1[0]) < 1e-8 * abs(l1[0])

@@ -1,0 +1,88 @@
+"""Test helpers: an independent numpy pruning implementation (different language, different
+underflow scheme: per-node max normalisation in log space) used to cross-check the C oracle."""
+import re
+
+import numpy as np
+
+from pepr_amd import synth
+
+AA = synth.AA
+
+
+def parse_newick(nw):
+    """Minimal parser -> nested (children, name, length)."""
+    s = nw.strip().rstrip(";")
+    pos = 0
+
+    def node():
+        nonlocal pos
+        kids = []
+        if s[pos] == "(":
+            pos += 1
+            while True:
+                kids.append(node())
+                if s[pos] == ",":
+                    pos += 1
+                    continue
+                if s[pos] == ")":
+                    pos += 1
+                    break
+        m = re.match(r"[^,():;]*", s[pos:])
+        name = m.group(0)
+        pos += len(name)
+        length = 0.0
+        if pos < len(s) and s[pos] == ":":
+            m = re.match(r":([-+0-9.eE]+)", s[pos:])
+            length = float(m.group(1))
+            pos += len(m.group(0))
+        return (kids, name, length)
+    return node()
+
+
+def numpy_lnl(names, rows, newick, alpha, pi_mode="raxml", ncat=4):
+    """Per-site lnL by pruning in numpy with log-space normalisation. Returns (total, per-site)."""
+    S, pi_full, pi_3 = synth.wag_constants()
+    pi = (pi_3 if pi_mode == "raxml" else pi_full)
+    pi = pi / pi.sum()
+    lam, U, Uinv = synth._eig(pi)
+    rates = synth.gamma_mean_rates(alpha, ncat) if ncat > 1 else np.ones(1)
+    idx = {n: i for i, n in enumerate(names)}
+    L = len(rows[0])
+    code = {c: i for i, c in enumerate(AA)}
+
+    def tipvec(row):
+        v = np.zeros((L, 20))
+        for s, ch in enumerate(row.upper()):
+            if ch in code:
+                v[s, code[ch]] = 1
+            elif ch == "B":
+                v[s, [2, 3]] = 1
+            elif ch == "Z":
+                v[s, [5, 6]] = 1
+            else:
+                v[s, :] = 1
+        return v
+
+    def P(t):
+        return np.stack([(U * np.exp(lam * r * t)[None, :]) @ Uinv for r in rates])   # [K,20,20]
+
+    def rec(nd):
+        kids, name, _ = nd
+        if not kids:
+            v = tipvec(rows[idx[name]])
+            return np.repeat(v[None], len(rates), 0), np.zeros(L)     # [K,L,20], logscale[L]
+        out = None
+        ls = np.zeros(L)
+        for k in kids:
+            cv, cl = rec(k)
+            x = np.einsum("kij,klj->kli", P(max(k[2], 0.0)), cv)
+            out = x if out is None else out * x
+            ls = ls + cl
+        mx = out.max(axis=(0, 2))
+        out = out / mx[None, :, None]
+        return out, ls + np.log(mx)
+
+    tree = parse_newick(newick)
+    cv, ls = rec(tree)
+    site = np.log((cv * pi[None, None, :]).sum(2).mean(0)) + ls
+    return site.sum(), site
