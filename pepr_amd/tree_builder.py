@@ -1,0 +1,239 @@
+"""Host-side mirror of the reference's tree-building interface for the hot path.
+
+Same names, argument meaning and error behaviour as the Java classes, so that the parity tests
+read like the reference's own call sites; every `run()` goes through the C ABI
+(include/peprml.h) to the HIP engine instead of spawning a process:
+
+  PhylogeneticTreeBuilder  <- .../pepr/tree/pipeline/PhylogeneticTreeBuilder.java:97-129,168-196,215-338
+  RAxMLRunner              <- .../pepr/tree/RAxMLRunner.java:64-152,162-213,320-336
+  FastTreeRunner           <- .../pepr/tree/FastTreeRunner.java:38-135,142-199,235
+
+Behaviour kept from the reference: a failed build leaves the result `None` (FastTreeRunner.java:
+125-131 logs and continues; callers see a null tree string); the ML matrix is a RAxML model
+string (default PROTGAMMAWAG, PhylogenomicPipeline2.java:248-250); threads/processes are accepted
+and ignored (the GPU engine needs no -T).  Not mirrored (out of scope): parsimony
+(-y), rapid bootstrap (-f a), nucleotide (-gtr -nt), constraints.
+"""
+import logging
+
+from . import engine
+
+ML, FAST_TREE, PARSIMONY, PARSIMONY_BL, NEIGHBOR_JOINING = "ml", "FastTree", "parsimony", "parsimony_bl", "nj"
+log = logging.getLogger("pepr_amd")
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = engine.Context(0)
+    return _default_ctx
+
+
+class SequenceAlignment:
+    """Minimal stand-in for .../pepr/alignment/SequenceAlignment.java: taxa + aligned char rows."""
+
+    def __init__(self, taxa, rows):
+        self.taxa = list(taxa)
+        self.rows = list(rows)
+
+    def getTaxa(self):
+        return self.taxa
+
+    def getLength(self):
+        return len(self.rows[0]) if self.rows else 0
+
+    def as_gene(self):
+        return (self.taxa, self.rows)
+
+
+def _model_from_matrix(matrix):
+    """RAxML -m strings PEPR passes (RAxMLRunner.java:115-132).  Only the WAG family is built."""
+    m = (matrix or "PROTGAMMAWAG").upper()
+    if not m.startswith("PROT") or "WAG" not in m:
+        raise ValueError("only PROT{GAMMA,CAT}WAG[F] is implemented on the GPU engine, got %r" % matrix)
+    return {"ncat": 4, "pi_mode": engine.PI_RAXML_3DP}
+
+
+class RAxMLRunner:
+    def __init__(self, threads=1, ctx=None):
+        self.threads = threads
+        self.ctx = ctx
+        self.alignment = None
+        self.matrix = "PROTGAMMAWAG"
+        self.bootstrapReps = 0
+        self.perSiteLL = False
+        self.perSiteLLTrees = None
+        self.bestTree = None
+        self.perSiteLLs = None
+        self.lnl = None
+        self.alpha = None
+        self.spr_radius = 5           # RAxML "best rearrangement setting 5" 
+
+    def setAlignment(self, a):
+        self.alignment = a
+
+    def getAlignment(self):
+        return self.alignment
+
+    def setMatrix(self, m):
+        self.matrix = m
+
+    def setBootstrapReps(self, reps):
+        self.bootstrapReps = reps
+
+    def setUseTaxonNames(self, b):
+        pass
+
+    def setPerSiteLogLikelihoods(self, b):
+        self.perSiteLL = b
+
+    def setPerSiteLLTrees(self, trees):
+        self.perSiteLLTrees = list(trees)
+
+    def run(self):
+        """-f d (ML search) or, with setPerSiteLogLikelihoods(true), -f g on the given trees."""
+        ctx = self.ctx or default_context()
+        try:
+            mdl = _model_from_matrix(self.matrix)
+            gene = self.alignment.as_gene()
+            if self.perSiteLL:
+                self.perSiteLLs = []
+                for nw in self.perSiteLLTrees:
+                    o = ctx.optimize([gene], [nw], **mdl)[0]        # RAxML -f g optimises model + lengths first
+                    r = ctx.score([gene], [o["newick"]], alpha=o["alpha"], site_lnl=True, **mdl)[0]
+                    self.perSiteLLs.append(r["site_lnl"])
+                return
+            if self.bootstrapReps:
+                raise ValueError("rapid bootstrap (-f a) is not on the GPU path; PEPR's jackknife uses reps=0")
+            r = ctx.search([gene], None, spr_radius=self.spr_radius, **mdl)[0]
+            self.bestTree, self.lnl, self.alpha = r["newick"], r["lnl"], r["alpha"]
+        except Exception as e:          # reference: rc logged, result stays null
+            log.error("RAxMLRunner failed: %s", e)
+            self.bestTree = None
+
+    def getBestTree(self):
+        return self.bestTree
+
+    def getPerSiteLLs(self):
+        return self.perSiteLLs
+
+
+class FastTreeRunner:
+    def __init__(self, ctx=None):
+        self.ctx = ctx
+        self.alignment = None
+        self.result = None
+        self.useRaxmlBranchLengths = False
+        self.bootstrapReps = 0
+        self.lnl = None
+
+    def setAlignment(self, a):
+        self.alignment = a
+
+    def getAlignment(self):
+        return self.alignment
+
+    def setUseRaxmlBranchLengths(self, b):
+        self.useRaxmlBranchLengths = b
+
+    def getUseRaxmlBranchLengths(self):
+        return self.useRaxmlBranchLengths
+
+    def setBootstrapReps(self, reps):
+        self.bootstrapReps = reps
+
+    def setRunName(self, n):
+        self.runName = n
+
+    def setThreadCount(self, n):
+        pass
+
+    def setNucleoide(self, nuc):
+        if nuc:
+            raise ValueError("nucleotide models are not on the GPU path")
+
+    def run(self):
+        """`FastTree_WAG -gamma -nosupport`: NJ start + NNI hill climbing under WAG+Gamma."""
+        ctx = self.ctx or default_context()
+        try:
+            r = ctx.search([self.alignment.as_gene()], None, nni=True, spr_radius=0, pi_mode=engine.PI_RAXML_3DP)[0]
+            self.result, self.lnl = r["newick"], r["lnl"]
+        except Exception as e:
+            log.error("FastTreeRunner failed: %s", e)
+            self.result = None
+
+    def getResult(self):
+        return self.result
+
+
+class PhylogeneticTreeBuilder:
+    def __init__(self, ctx=None):
+        self.ctx = ctx
+        self.alignment = None
+        self.treeBuildingMethod = ML
+        self.mlMatrix = "PROTGAMMAWAG"
+        self.treeString = None
+        self.processes = 1
+        self.bootstrapReps = 0
+        self.runName = None
+        self._useRaxmlBL = False
+        self.constraintTree = None
+
+    def setAlignment(self, a):
+        self.alignment = a
+
+    def getAlignment(self):
+        return self.alignment
+
+    def setTreeBuildingMethod(self, m):
+        self.treeBuildingMethod = m
+
+    def setMLMatrix(self, m):
+        self.mlMatrix = m
+
+    def setProcesses(self, n):
+        self.processes = n
+
+    def setBootstrapReps(self, reps):
+        self.bootstrapReps = reps
+
+    def getBootstrapReps(self):
+        return self.bootstrapReps
+
+    def setRunName(self, n):
+        self.runName = n
+
+    def getRunName(self):
+        return self.runName
+
+    def useRaxmlBranchLengths(self, b):
+        self._useRaxmlBL = b
+
+    def setConstraintTree(self, t):
+        self.constraintTree = t
+
+    def setNucleotide(self, nuc):
+        if nuc:
+            raise ValueError("nucleotide models are not on the GPU path")
+
+    def setTreeString(self, s):
+        self.treeString = s
+
+    def getTreeString(self):
+        return self.treeString
+
+    def run(self):
+        if self.treeBuildingMethod == ML:
+            r = RAxMLRunner(self.processes, self.ctx)
+            r.setBootstrapReps(self.bootstrapReps); r.setAlignment(self.alignment); r.setMatrix(self.mlMatrix)
+            r.run()
+            self.setTreeString(r.getBestTree())
+        elif self.treeBuildingMethod == FAST_TREE:
+            f = FastTreeRunner(self.ctx)
+            f.setAlignment(self.alignment); f.setRunName(self.runName); f.setBootstrapReps(self.bootstrapReps)
+            f.setUseRaxmlBranchLengths(self._useRaxmlBL)
+            f.run()
+            self.setTreeString(f.getResult())
+        else:
+            raise ValueError("tree building method %r is outside the GPU path (ml, FastTree)" % self.treeBuildingMethod)
