@@ -131,7 +131,8 @@ int pml_rf_distance(const char *newick_a, const char *newick_b, int *rf_out);
 
 /* profiling: HIP-event time of device kernels since the last reset (cfg.profile = 1) */
 enum { PML_K_PMAT = 0, PML_K_NEWVIEW = 1, PML_K_EVALUATE = 2, PML_K_SUMTABLE = 3, PML_K_NEWTON = 4,
-       PML_K_REDUCE = 5, PML_K_COUNT = 6 };
+       PML_K_REDUCE = 5,
+       PML_K_HOST_BUILD = 6 /* CPU ms building descriptors */, PML_K_HOST_WAIT = 7 /* CPU ms in stream sync */, PML_K_COUNT = 8 };
 int pml_kernel_stats(pml_ctx *ctx, int kernel, long long *launches, double *total_ms,
                      double *algo_bytes /* algorithmic bytes moved, SURVEY 8d figures */);
 int pml_kernel_stats_reset(pml_ctx *ctx);

@@ -9,6 +9,7 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -263,7 +264,12 @@ int Batch::need(int g, int v, int to, std::vector<PendingOp> &ops) {
 // ------------------------------------------------------------------------------------------
 // run: one upload, pmat, newview levels, tails, one sync
 // ------------------------------------------------------------------------------------------
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
+    const double t_begin = now_ms();
     HIPCHK(hipSetDevice(ctx->device));
     // group by gene, keeping each gene's dependency order (children are emitted before parents)
     std::stable_sort(ops.begin(), ops.end(), [](const PendingOp &a, const PendingOp &b) { return a.gene < b.gene; });
@@ -392,8 +398,12 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     }
     if (!tails.empty())
         HIPCHK(hipMemcpyAsync(h_scalars, d_scalars, sizeof(double) * 8 * genes.size(), hipMemcpyDeviceToHost, ctx->stream));
+    const double t_launched = now_ms();
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
+    const double t_done = now_ms();
+    ctx->stats[K_HOST_BUILD].launches++; ctx->stats[K_HOST_BUILD].ms += t_launched - t_begin;
+    ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += t_done - t_launched;
     ctx->resolve_events();
     for (auto &o : ops) { Gene &G = genes[o.gene]; G.valid[o.idx] = 1; G.pend_level[o.idx] = -1; }
     return 0;

@@ -11,7 +11,7 @@
 
 namespace pml {
 
-enum { K_PMAT = 0, K_NEWVIEW = 1, K_EVALUATE = 2, K_SUMTABLE = 3, K_NEWTON = 4, K_REDUCE = 5, K_COUNT = 6 };
+enum { K_PMAT = 0, K_NEWVIEW = 1, K_EVALUATE = 2, K_SUMTABLE = 3, K_NEWTON = 4, K_REDUCE = 5, K_HOST_BUILD = 6, K_HOST_WAIT = 7, K_COUNT = 8 };
 
 struct Ctx {
     int device = 0;

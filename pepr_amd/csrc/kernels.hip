@@ -26,6 +26,8 @@
 // RAxML 7.2.5, SURVEY.md section 8a-11 iii-v).
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace pml {
 
 #define TWO_P256 1.15792089237316195423570985008687907853269984665640564039457584007913129639936e77
@@ -91,137 +93,167 @@ __global__ __launch_bounds__(256) void k_eigfrags(const ModelDev *__restrict__ m
 //   MODE_SUMTABLE: same contraction with the eigen-basis matrices (no rescue), counts = l + r
 //   MODE_EVALUATE: per-pattern ln( 1/4 sum_c sum_s L_c[s] (pi P_c . R_c)[s] ) - counts*256 ln 2
 // ------------------------------------------------------------------------------------------
-struct Operand {            // one child's 5 double2 B operands of one category
-    double2 v[5];
+typedef double dvec2 __attribute__((ext_vector_type(2)));   // native vectors: loadable from address_space(1)
+typedef int ivec2 __attribute__((ext_vector_type(2)));
+struct Operand {            // one child's 5 two-pattern B operands of one category
+    dvec2 v[5];
 };
 
-template <bool TIP>
-__device__ __forceinline__ void load_operand(Operand &o, const double *__restrict__ base, size_t M, int c, int q, int p,
-                                             unsigned m0, unsigned m1) {
-#pragma unroll
-    for (int kk = 0; kk < 5; ++kk) {
-        const int st = kk * 4 + q;
-        if (TIP) o.v[kk] = make_double2((m0 >> st) & 1u ? 1.0 : 0.0, (m1 >> st) & 1u ? 1.0 : 0.0);
-        else o.v[kk] = *reinterpret_cast<const double2 *>(base + (size_t)(c * NS + st) * M + p);
-    }
-}
+typedef const __attribute__((address_space(1))) char *gcptr;    // explicit GLOBAL pointers: pointers read
+typedef __attribute__((address_space(1))) char *gptr;           // from a descriptor are generic -> flat_load
+#define GLOBAL_AS __attribute__((address_space(1)))
 
-// acc[st][0/1] = sum_kk frag(c,st,kk) x operand(kk)   (even / odd pattern of the lane)
-__device__ __forceinline__ void contract(double (&acc)[5][2], const double *__restrict__ frag_c, const Operand &o) {
-#pragma unroll
-    for (int st = 0; st < 5; ++st) { acc[st][0] = 0.0; acc[st][1] = 0.0; }
+// CLV operand: base is wave-uniform (SGPR pair), lane_off the lane's 32-bit byte offset
+// (q*M + p)*8, so the loads compile to the saddr + voffset form without per-row VGPR addresses.
+__device__ __forceinline__ void load_clv(Operand &o, gcptr base, unsigned lane_off, size_t rowbytes, int c) {
 #pragma unroll
     for (int kk = 0; kk < 5; ++kk)
+        o.v[kk] = *reinterpret_cast<const GLOBAL_AS dvec2 *>(base + (size_t)(c * NS + kk * 4) * rowbytes + lane_off);
+}
+// tip operand: 0/1 indicator rows from the LDS table T[code][state] (same for every category)
+__device__ __forceinline__ void load_tip(Operand &o, const float *__restrict__ T, unsigned codes, int q) {
+    const float *t0 = T + (codes & 0xFFu) * NS + q, *t1 = T + (codes >> 8) * NS + q;
 #pragma unroll
-        for (int st = 0; st < 5; ++st) {
-            const double a = frag_c[(st * 5 + kk) * 16];
-            acc[st][0] = mfma4(a, o.v[kk].x, acc[st][0]);
-            acc[st][1] = mfma4(a, o.v[kk].y, acc[st][1]);
-        }
+    for (int kk = 0; kk < 5; ++kk) o.v[kk] = (dvec2){(double)t0[kk * 4], (double)t1[kk * 4]};
 }
 
-template <int MODE, bool LTIP, bool RTIP>
-__device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restrict__ sP, int p, int lane) {
+// acc[st][0/1] = sum_kk frag(c,st,kk) x operand(kk)   (even / odd pattern of the lane).
+// The A fragments are software-pipelined one k-step ahead and fenced with sched_barrier so that
+// hipcc does not hoist all 25 ds_reads (50 VGPRs) in front of the MFMAs.
+__device__ __forceinline__ void contract(double (&acc)[5][2], const double *__restrict__ frag_c, const Operand &o) {
+    double a_cur[5], a_nxt[5];
+#pragma unroll
+    for (int st = 0; st < 5; ++st) { acc[st][0] = 0.0; acc[st][1] = 0.0; a_cur[st] = frag_c[(st * 5) * 16]; }
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) {
+        if (kk < 4) {
+#pragma unroll
+            for (int st = 0; st < 5; ++st) a_nxt[st] = frag_c[(st * 5 + kk + 1) * 16];
+        }
+#pragma unroll
+        for (int st = 0; st < 5; ++st) {
+            acc[st][0] = mfma4(a_cur[st], o.v[kk].x, acc[st][0]);
+            acc[st][1] = mfma4(a_cur[st], o.v[kk].y, acc[st][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int st = 0; st < 5; ++st) a_cur[st] = a_nxt[st];
+    }
+}
+
+// One op on one chunk (32 patterns) of one wave.  All branches on op.* are wave-uniform.
+//   MODE_NEWVIEW : out[c][s] = (P_L,c . L_c)[s] * (P_R,c . R_c)[s], 2^256 rescue, scaling counts
+//   MODE_SUMTABLE: same contraction with the eigen-basis matrices (no rescue), counts = l + r
+//   MODE_EVALUATE: per-pattern ln( 1/4 sum_c sum_s L_c[s] (pi P_c . R_c)[s] ) - counts*256 ln 2
+template <bool PREFETCH>
+__device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restrict__ sP, const float *__restrict__ sT,
+                                         int p, int lane) {
     const int q = lane >> 4;
-    const size_t M = (size_t)op.mpad;
-    const double *__restrict__ Lp = static_cast<const double *>(op.left);
-    const double *__restrict__ Rp = static_cast<const double *>(op.right);
-    unsigned mL0 = 0, mL1 = 0, mR0 = 0, mR1 = 0;
-    if (LTIP) {
-        const unsigned cc = *reinterpret_cast<const unsigned short *>(static_cast<const unsigned char *>(op.left) + p);
-        mL0 = code_mask(cc & 0xFFu); mL1 = code_mask(cc >> 8);
-    }
-    if (RTIP) {
-        const unsigned cc = *reinterpret_cast<const unsigned short *>(static_cast<const unsigned char *>(op.right) + p);
-        mR0 = code_mask(cc & 0xFFu); mR1 = code_mask(cc >> 8);
-    }
+    const size_t rowbytes = (size_t)op.mpad * 8;
+    const unsigned lane_off = (unsigned)((size_t)q * rowbytes) + (unsigned)p * 8u;
+    const bool ltip = op.flags & 1, rtip = op.flags & 2;
+    const int mode = op.mode;
+    gcptr Lp = (gcptr)op.left, Rp = (gcptr)op.right;
+    gptr O = (gptr)op.out;
     // lane's A-fragment element: 4*k + i with k = q, i = lane&3
     const double *fL = sP + (q * 4 + (lane & 3));
     const double *fR = fL + PFRAG;
     double mx0 = 0.0, mx1 = 0.0, site0 = 0.0, site1 = 0.0;
 
     Operand curL, curR, nxtL, nxtR;
-    load_operand<LTIP>(curL, Lp, M, 0, q, p, mL0, mL1);     // evaluate: left side in output layout
-    load_operand<RTIP>(curR, Rp, M, 0, q, p, mR0, mR1);
-#pragma unroll
+    if (ltip) load_tip(curL, sT, *reinterpret_cast<const GLOBAL_AS unsigned short *>(Lp + p), q);
+    else load_clv(curL, Lp, lane_off, rowbytes, 0);           // evaluate: left side in output layout
+    if (rtip) load_tip(curR, sT, *reinterpret_cast<const GLOBAL_AS unsigned short *>(Rp + p), q);
+    else load_clv(curR, Rp, lane_off, rowbytes, 0);
+#pragma unroll 1
     for (int c = 0; c < NCAT; ++c) {
-        if (c + 1 < NCAT) {                                 // software prefetch of the next category
-            load_operand<LTIP>(nxtL, Lp, M, c + 1, q, p, mL0, mL1);
-            load_operand<RTIP>(nxtR, Rp, M, c + 1, q, p, mR0, mR1);
+        if (PREFETCH && c + 1 < NCAT) {                       // software prefetch of the next category
+            if (!ltip) load_clv(nxtL, Lp, lane_off, rowbytes, c + 1);
+            if (!rtip) load_clv(nxtR, Rp, lane_off, rowbytes, c + 1);
         }
         double aR[5][2];
         contract(aR, fR + c * 25 * 16, curR);
-        if (MODE == MODE_EVALUATE) {
+        if (mode == MODE_EVALUATE) {
 #pragma unroll
             for (int st = 0; st < 5; ++st) { site0 += curL.v[st].x * aR[st][0]; site1 += curL.v[st].y * aR[st][1]; }
         } else {
             double aL[5][2];
             contract(aL, fL + c * 25 * 16, curL);
-            double *__restrict__ O = op.out;
 #pragma unroll
             for (int st = 0; st < 5; ++st) {
                 const double o0 = aL[st][0] * aR[st][0], o1 = aL[st][1] * aR[st][1];
                 mx0 = fmax(mx0, o0); mx1 = fmax(mx1, o1);
-                *reinterpret_cast<double2 *>(O + (size_t)(c * NS + st * 4 + q) * M + p) = make_double2(o0, o1);
+                *reinterpret_cast<GLOBAL_AS dvec2 *>(O + (size_t)(c * NS + st * 4) * rowbytes + lane_off) = (dvec2){o0, o1};
             }
         }
-        if (c + 1 < NCAT) { curL = nxtL; curR = nxtR; }
+        if (c + 1 < NCAT) {
+            if (PREFETCH) { if (!ltip) curL = nxtL; if (!rtip) curR = nxtR; }
+            else {
+                if (!ltip) load_clv(curL, Lp, lane_off, rowbytes, c + 1);
+                if (!rtip) load_clv(curR, Rp, lane_off, rowbytes, c + 1);
+            }
+        }
     }
 
-    int2 sc = make_int2(0, 0);
+    ivec2 sc = {0, 0};
     if (q == 0) {
-        if (!LTIP) { const int2 a = *reinterpret_cast<const int2 *>(op.l_scl + p); sc.x += a.x; sc.y += a.y; }
-        if (!RTIP) { const int2 a = *reinterpret_cast<const int2 *>(op.r_scl + p); sc.x += a.x; sc.y += a.y; }
+        if (!ltip) sc += *reinterpret_cast<const GLOBAL_AS ivec2 *>((gcptr)op.l_scl + 4 * p);
+        if (!rtip) sc += *reinterpret_cast<const GLOBAL_AS ivec2 *>((gcptr)op.r_scl + 4 * p);
     }
-    if (MODE == MODE_NEWVIEW) {
+    if (mode == MODE_NEWVIEW) {
         mx0 = fmax(mx0, __shfl_xor(mx0, 16)); mx0 = fmax(mx0, __shfl_xor(mx0, 32));
         mx1 = fmax(mx1, __shfl_xor(mx1, 16)); mx1 = fmax(mx1, __shfl_xor(mx1, 32));
         const bool n0 = mx0 < TWO_M256, n1 = mx1 < TWO_M256;
         if (__any(n0 || n1)) {               // rare: numerical rescue of underflowing patterns
             if (n0 || n1) {
-                double *O = op.out;
-                for (int c = 0; c < NCAT; ++c)
-                    for (int st = 0; st < 5; ++st) {
-                        double2 *ptr = reinterpret_cast<double2 *>(O + (size_t)(c * NS + st * 4 + q) * M + p);
-                        double2 v = *ptr;
-                        if (n0) v.x *= TWO_P256;
-                        if (n1) v.y *= TWO_P256;
-                        *ptr = v;
-                    }
+#pragma unroll 1
+                for (int r = 0; r < NCAT * 5; ++r) {
+                    GLOBAL_AS dvec2 *ptr = reinterpret_cast<GLOBAL_AS dvec2 *>(O + (size_t)((r / 5) * NS + (r % 5) * 4) * rowbytes + lane_off);
+                    dvec2 v = *ptr;
+                    if (n0) v.x *= TWO_P256;
+                    if (n1) v.y *= TWO_P256;
+                    *ptr = v;
+                }
             }
         }
-        if (q == 0) { sc.x += n0 ? 1 : 0; sc.y += n1 ? 1 : 0; *reinterpret_cast<int2 *>(op.out_scl + p) = sc; }
-    } else if (MODE == MODE_SUMTABLE) {
-        if (q == 0) *reinterpret_cast<int2 *>(op.out_scl + p) = sc;
+        if (q == 0) { sc.x += n0 ? 1 : 0; sc.y += n1 ? 1 : 0; *reinterpret_cast<GLOBAL_AS ivec2 *>((gptr)op.out_scl + 4 * p) = sc; }
+    } else if (mode == MODE_SUMTABLE) {
+        if (q == 0) *reinterpret_cast<GLOBAL_AS ivec2 *>((gptr)op.out_scl + 4 * p) = sc;
     } else {
         site0 += __shfl_xor(site0, 16); site0 += __shfl_xor(site0, 32);
         site1 += __shfl_xor(site1, 16); site1 += __shfl_xor(site1, 32);
         if (q == 0) {
             const double l0 = log(site0 * 0.25) - sc.x * LOG_2_256;
             const double l1 = log(site1 * 0.25) - sc.y * LOG_2_256;
-            *reinterpret_cast<double2 *>(op.out + p) = make_double2(l0, l1);
+            *reinterpret_cast<GLOBAL_AS dvec2 *>(O + 8 * p) = (dvec2){l0, l1};
         }
-    }
-}
-
-template <int MODE>
-__device__ __forceinline__ void chunk_dispatch(const NvOp &op, const double *sP, int p, int lane) {
-    switch (op.flags & 3) {
-        case 0: chunk_op<MODE, false, false>(op, sP, p, lane); break;
-        case 1: chunk_op<MODE, true, false>(op, sP, p, lane); break;
-        case 2: chunk_op<MODE, false, true>(op, sP, p, lane); break;
-        default: chunk_op<MODE, true, true>(op, sP, p, lane); break;
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // k_oplist: workgroup (gene, pattern block of 128) executes the gene's op list in order.
+// VARIANT bit0: low-register form (no category prefetch)
+//         bit1: double-buffered fragment staging by LDS-DMA (one barrier per op)
 // ------------------------------------------------------------------------------------------
 constexpr int PAT_PER_WG = 4 * PAT_PER_WAVE;   // 128
+constexpr int TIPTAB = NCODES * NS;            // 460 floats
 
-__global__ __launch_bounds__(256, 2) void k_oplist(const NvOp *__restrict__ ops,
-                                                   const GeneRun *__restrict__ runs, int blocks_per_gene) {
-    __shared__ double sP[2 * PFRAG];   // 25.6 KB: [left|right][cat][st][kk][16]
+__device__ __forceinline__ void stage_frags_dma(const NvOp &op, double *dst, int lane, int wave) {
+    // 2*PFRAG doubles = 25 KiB = 25 wave-instructions of 1 KiB (16 B per lane)
+    for (int i = wave; i < 25; i += 4) {
+        const int e = i * 128 + lane * 2;      // element index of this lane's 16 bytes in [left|right]
+        const double *g = (e < PFRAG) ? op.pl + e : op.pr + (e - PFRAG);
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)g, (__attribute__((address_space(3))) void *)(dst + i * 128), 16, 0, 0);
+    }
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : 3) void k_oplist(
+        const NvOp *__restrict__ ops, const GeneRun *__restrict__ runs, int blocks_per_gene) {
+    constexpr bool PREFETCH = !(VARIANT & 1);
+    constexpr bool DBUF = (VARIANT & 2) != 0;
+    __shared__ double sP[(DBUF ? 2 : 1) * 2 * PFRAG + TIPTAB / 2];   // 25.6 KB per fragment buffer + tip table
+    float *sT = reinterpret_cast<float *>(sP + (DBUF ? 2 : 1) * 2 * PFRAG);
     const int gi = blockIdx.x / blocks_per_gene, blk = blockIdx.x % blocks_per_gene;
     const GeneRun run = runs[gi];
     if (run.op_begin >= run.op_end) return;
@@ -231,10 +263,18 @@ __global__ __launch_bounds__(256, 2) void k_oplist(const NvOp *__restrict__ ops,
     const int p = (blk * 4 + wave) * PAT_PER_WAVE + 2 * (lane & 15);
     const bool active = (blk * 4 + wave) * PAT_PER_WAVE < mpad;
 
+    for (int i = tid; i < TIPTAB; i += 256) sT[i] = (code_mask(i / NS) >> (i % NS)) & 1u ? 1.0f : 0.0f;
+    if (DBUF) stage_frags_dma(ops[run.op_begin], sP, lane, wave);
+    __syncthreads();
     for (int oi = run.op_begin; oi < run.op_end; ++oi) {
         const NvOp op = ops[oi];
-        __syncthreads();                 // previous op: LDS reads and global stores complete
-        {
+        const double *buf = sP;
+        if (DBUF) {
+            const int par = (oi - run.op_begin) & 1;
+            buf = sP + par * 2 * PFRAG;
+            if (oi + 1 < run.op_end) stage_frags_dma(ops[oi + 1], sP + (par ^ 1) * 2 * PFRAG, lane, wave);
+        } else {
+            if (oi > run.op_begin) __syncthreads();      // previous op: LDS reads and global stores complete
             const double2 *gl = reinterpret_cast<const double2 *>(op.pl);
             const double2 *gr = reinterpret_cast<const double2 *>(op.pr);
             double2 *s2 = reinterpret_cast<double2 *>(sP);
@@ -242,13 +282,10 @@ __global__ __launch_bounds__(256, 2) void k_oplist(const NvOp *__restrict__ ops,
                 if (op.mode != MODE_EVALUATE) s2[i] = gl[i];
                 s2[PFRAG / 2 + i] = gr[i];
             }
+            __syncthreads();
         }
-        __syncthreads();
-        if (active) {
-            if (op.mode == MODE_NEWVIEW) chunk_dispatch<MODE_NEWVIEW>(op, sP, p, lane);
-            else if (op.mode == MODE_SUMTABLE) chunk_dispatch<MODE_SUMTABLE>(op, sP, p, lane);
-            else chunk_dispatch<MODE_EVALUATE>(op, sP, p, lane);
-        }
+        if (active) chunk_op<PREFETCH>(op, buf, sT, p, lane);
+        if (DBUF) __syncthreads();           // next fragments landed (vmcnt(0) + barrier), stores done
     }
 }
 
@@ -357,10 +394,21 @@ void launch_pmat(const ModelDev *model, const PmatReq *reqs, double *frags, int 
 void launch_eigfrags(const ModelDev *model, double *frags2, hipStream_t s) {
     hipLaunchKernelGGL(k_eigfrags, dim3(1), dim3(256), 0, s, model, frags2);
 }
+static int oplist_variant() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PML_OPLIST_VARIANT"); v = e ? atoi(e) & 3 : 1; }
+    return v;
+}
 void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, hipStream_t s) {
     if (nruns <= 0) return;
     const int bpg = (max_mpad + PAT_PER_WG - 1) / PAT_PER_WG;
-    hipLaunchKernelGGL(k_oplist, dim3((unsigned)(nruns * bpg)), dim3(256), 0, s, ops, runs, bpg);
+    const dim3 grid((unsigned)(nruns * bpg)), block(256);
+    switch (oplist_variant()) {
+        case 0: hipLaunchKernelGGL(k_oplist<0>, grid, block, 0, s, ops, runs, bpg); break;
+        case 1: hipLaunchKernelGGL(k_oplist<1>, grid, block, 0, s, ops, runs, bpg); break;
+        case 2: hipLaunchKernelGGL(k_oplist<2>, grid, block, 0, s, ops, runs, bpg); break;
+        default: hipLaunchKernelGGL(k_oplist<3>, grid, block, 0, s, ops, runs, bpg); break;
+    }
 }
 void launch_reduce(const ReduceReq *reqs, int n, hipStream_t s) {
     if (n <= 0) return;

@@ -8,7 +8,8 @@ import numpy as np
 
 from . import _lib
 
-KERNELS = {"pmat": 0, "newview": 1, "evaluate": 2, "sumtable": 3, "newton": 4, "reduce": 5}
+KERNELS = {"pmat": 0, "newview": 1, "evaluate": 2, "sumtable": 3, "newton": 4, "reduce": 5,
+           "host_build": 6, "host_wait": 7}
 PI_RAXML_3DP, PI_WAG_FULL = 0, 1
 
 
