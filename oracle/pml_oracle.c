@@ -556,16 +556,12 @@ static side eng_side(po_engine *e, const po_tree *t, int v, int to) {
 static void eng_pmats(const po_engine *e, double t, double P[][PO_NS][PO_NS]) {
     for (int c = 0; c < e->K; c++) po_pmatrix(e->m, t * e->rates[c], P[c]);
 }
-static void eng_newview(po_engine *e, const po_tree *t, int v, int k) {
-    int idx = (v - e->ntax) * 3 + k, K = e->K, np = e->npat;
-    int ch[2], ci = 0; double bl[2];
-    for (int q = 0; q < 3; q++) if (q != k) { ch[ci] = t->nbr[v][q]; bl[ci] = t->len[v][q]; ci++; }
-    side L = eng_side(e, t, ch[0], v), R = eng_side(e, t, ch[1], v);
-    if (!e->clv[idx]) { e->clv[idx] = (double *)malloc(sizeof(double) * (size_t)np * K * 20); e->scl[idx] = (int *)malloc(sizeof(int) * np); }
+/* generic CLV combination: out = (P(bl0).L) * (P(bl1).R) with the 2^256 rescue */
+static void nv_core(po_engine *e, side L, side R, double bl0, double bl1, double *out, int *osc) {
+    int K = e->K, np = e->npat;
     double (*PL)[PO_NS][PO_NS] = (double (*)[PO_NS][PO_NS])malloc(sizeof(double[PO_NS][PO_NS]) * K);
     double (*PR)[PO_NS][PO_NS] = (double (*)[PO_NS][PO_NS])malloc(sizeof(double[PO_NS][PO_NS]) * K);
-    eng_pmats(e, bl[0], PL); eng_pmats(e, bl[1], PR);
-    double *out = e->clv[idx]; int *osc = e->scl[idx];
+    eng_pmats(e, bl0, PL); eng_pmats(e, bl1, PR);
     const double two256 = ldexp(1.0, 256), thresh = ldexp(1.0, -256);
     for (int p = 0; p < np; p++) {
         double mx = 0.0;
@@ -584,7 +580,16 @@ static void eng_newview(po_engine *e, const po_tree *t, int v, int k) {
         osc[p] = sc;
     }
     free(PL); free(PR);
-    e->valid[idx] = 1; e->n_newview++;
+    e->n_newview++;
+}
+static void eng_newview(po_engine *e, const po_tree *t, int v, int k) {
+    int idx = (v - e->ntax) * 3 + k, K = e->K, np = e->npat;
+    int ch[2], ci = 0; double bl[2];
+    for (int q = 0; q < 3; q++) if (q != k) { ch[ci] = t->nbr[v][q]; bl[ci] = t->len[v][q]; ci++; }
+    side L = eng_side(e, t, ch[0], v), R = eng_side(e, t, ch[1], v);
+    if (!e->clv[idx]) { e->clv[idx] = (double *)malloc(sizeof(double) * (size_t)np * K * 20); e->scl[idx] = (int *)malloc(sizeof(int) * np); }
+    nv_core(e, L, R, bl[0], bl[1], e->clv[idx], e->scl[idx]);
+    e->valid[idx] = 1;
 }
 static void eng_bind(po_engine *e, const po_tree *t) { if (e->bound != t) { e->bound = t; eng_invalidate_all(e); } }
 
@@ -625,10 +630,9 @@ double po_engine_site_lnl(po_engine *e, const po_tree *t, double *site_lnl) {
     free(pl); return tot;
 }
 
-/* sumtable for branch (u,v): S[p][c][i] = (sum_s pi_s A[s] U[s][i]) * (sum_j Uinv[i][j] B[j]) */
-static void eng_sumtable(po_engine *e, const po_tree *t, int u, int v, int *scale_out) {
+/* sumtable for two sides: S[p][c][i] = (sum_s pi_s A[s] U[s][i]) * (sum_j Uinv[i][j] B[j]) */
+static void sumtable_core(po_engine *e, side A, side B, int *scale_out) {
     int K = e->K, np = e->npat;
-    side A = eng_side(e, t, u, v), B = eng_side(e, t, v, u);
     for (int p = 0; p < np; p++) {
         for (int c = 0; c < K; c++) {
             const double *xa = A.clv ? A.clv + ((size_t)p * K + c) * 20 : e->tipvec[A.codes[p]];
@@ -642,6 +646,10 @@ static void eng_sumtable(po_engine *e, const po_tree *t, int u, int v, int *scal
         }
         if (scale_out) scale_out[p] = (A.scl ? A.scl[p] : 0) + (B.scl ? B.scl[p] : 0);
     }
+}
+static void eng_sumtable(po_engine *e, const po_tree *t, int u, int v, int *scale_out) {
+    side A = eng_side(e, t, u, v), B = eng_side(e, t, v, u);
+    sumtable_core(e, A, B, scale_out);
 }
 /* lnL (without scaling constant), d1, d2 at branch length tt from the sumtable */
 static void eng_core_derivs(po_engine *e, double tt, const int *scale, double *lnl, double *d1, double *d2) {
@@ -796,4 +804,153 @@ double po_bruteforce_lnl(const po_aln *a, const po_model *m, int K, double alpha
     }
     free(P);
     return total;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * start tree: neighbour joining on Kimura-corrected protein distances
+ *   d = -ln max(1 - p - 0.2 p^2, 0.05) over positions where both residues are unambiguous
+ *   (3.0 when nothing is comparable); first minimum of the Q criterion wins ties.
+ * ---------------------------------------------------------------------------------------- */
+po_tree *po_nj_tree(const po_aln *a) {
+    int n = a->ntax, N = 2 * n - 2, np = a->npat, i, j, p;
+    double *D = (double *)calloc((size_t)N * N, sizeof(double));
+    for (i = 0; i < n; i++)
+        for (j = i + 1; j < n; j++) {
+            double cmp = 0, diff = 0;
+            const unsigned char *ci = a->codes + (size_t)i * np, *cj = a->codes + (size_t)j * np;
+            for (p = 0; p < np; p++) if (ci[p] < 20 && cj[p] < 20) { cmp += a->weight[p]; if (ci[p] != cj[p]) diff += a->weight[p]; }
+            double d = 3.0;
+            if (cmp > 0) { double pd = diff / cmp, x = 1.0 - pd - 0.2 * pd * pd; d = -log(x > 0.05 ? x : 0.05); }
+            D[(size_t)i * N + j] = D[(size_t)j * N + i] = d;
+        }
+    po_tree *t = t_alloc(n);
+    int *act = (int *)malloc(sizeof(int) * n), m = n, next = n;
+    double *r = (double *)calloc(N, sizeof(double));
+    for (i = 0; i < n; i++) act[i] = i;
+#define NJCLAMP(x) ((x) < PO_TMIN ? PO_TMIN : ((x) > PO_TMAX ? PO_TMAX : (x)))
+    while (m > 3) {
+        for (i = 0; i < m; i++) { double s = 0; for (j = 0; j < m; j++) s += D[(size_t)act[i] * N + act[j]]; r[act[i]] = s; }
+        double best = 1e300; int bi = 0, bj = 1;
+        for (i = 0; i < m; i++) for (j = i + 1; j < m; j++) {
+            int x = act[i], y = act[j];
+            double q = (m - 2) * D[(size_t)x * N + y] - r[x] - r[y];
+            if (q < best) { best = q; bi = i; bj = j; }
+        }
+        int x = act[bi], y = act[bj], u = next++;
+        double dxy = D[(size_t)x * N + y], lx = 0.5 * dxy + (r[x] - r[y]) / (2.0 * (m - 2));
+        t_connect(t, u, x, NJCLAMP(lx)); t_connect(t, u, y, NJCLAMP(dxy - lx));
+        for (i = 0; i < m; i++) { int z = act[i]; if (z == x || z == y) continue; double d = 0.5 * (D[(size_t)x * N + z] + D[(size_t)y * N + z] - dxy); D[(size_t)u * N + z] = D[(size_t)z * N + u] = d; }
+        act[bi] = u; for (i = bj; i + 1 < m; i++) act[i] = act[i + 1]; m--;
+    }
+    {
+        int x = act[0], y = act[1], z = act[2], u = next++;
+        double dxy = D[(size_t)x * N + y], dxz = D[(size_t)x * N + z], dyz = D[(size_t)y * N + z];
+        t_connect(t, u, x, NJCLAMP(0.5 * (dxy + dxz - dyz))); t_connect(t, u, y, NJCLAMP(0.5 * (dxy + dyz - dxz))); t_connect(t, u, z, NJCLAMP(0.5 * (dxz + dyz - dxy)));
+    }
+    free(D); free(act); free(r);
+    return t;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * topology search (spec mirrored by pepr_amd/csrc/search.cpp, DESIGN.md "Search")
+ * ---------------------------------------------------------------------------------------- */
+#define NNI_MIN_GAIN 0.01
+typedef struct { int u, v, alt; double gain, t; int order; } nni_cand;
+static int cand_cmp(const void *a, const void *b) {
+    const nni_cand *x = (const nni_cand *)a, *y = (const nni_cand *)b;
+    if (x->gain > y->gain) return -1; if (x->gain < y->gain) return 1;
+    return x->order - y->order;
+}
+static void others(const po_tree *t, int v, int excl, int out[2], double len[2]) {
+    int ci = 0; for (int q = 0; q < 3; q++) if (t->nbr[v][q] != excl) { out[ci] = t->nbr[v][q]; len[ci] = t->len[v][q]; ci++; }
+}
+/* swap subtree x (neighbour of u) with subtree y (neighbour of v); slots keep their position */
+static void tree_swap(po_tree *t, int u, int x, int v, int y) {
+    int ku = slot_of(t, u, x), kv = slot_of(t, v, y), kx = slot_of(t, x, u), ky = slot_of(t, y, v);
+    double lx = t->len[u][ku], ly = t->len[v][kv];
+    t->nbr[u][ku] = y; t->len[u][ku] = ly; t->nbr[v][kv] = x; t->len[v][kv] = lx;
+    t->nbr[x][kx] = v; t->nbr[y][ky] = u;
+}
+static void nni_apply(po_tree *t, int u, int v, int alt, double tnew) {
+    int a[2], c[2]; double la[2], lc[2];
+    others(t, u, v, a, la); others(t, v, u, c, lc);
+    tree_swap(t, u, a[1], v, alt == 1 ? c[0] : c[1]);
+    tree_set_len(t, u, v, tnew);
+}
+static void tree_assign(po_tree *dst, const po_tree *src) {
+    memcpy(dst->nbr, src->nbr, sizeof(int[3]) * src->nnodes); memcpy(dst->len, src->len, sizeof(double[3]) * src->nnodes);
+}
+static double light_smooth(po_engine *e, po_tree *t) {
+    for (int pass = 0; pass < 2; pass++) if (eng_smooth(e, t) < 1e-3) break;
+    return po_engine_lnl(e, t, NULL);
+}
+/* one NNI round; returns number of applied moves, updates *lnl */
+static int nni_round(po_engine *e, po_tree *t, double *lnl) {
+    int n = e->ntax, np = e->npat, K = e->K, ncand = 0, i;
+    nni_cand *cands = (nni_cand *)malloc(sizeof(nni_cand) * (size_t)(n > 3 ? n - 3 : 1));
+    double *X = (double *)malloc(sizeof(double) * (size_t)np * K * 20), *Y = (double *)malloc(sizeof(double) * (size_t)np * K * 20);
+    int *xs = (int *)malloc(sizeof(int) * np), *ys = (int *)malloc(sizeof(int) * np), *sc = (int *)malloc(sizeof(int) * np);
+    for (int u = n; u < t->nnodes; u++) for (int k = 0; k < 3; k++) {
+        int v = t->nbr[u][k]; if (v < n || v < u) continue;
+        int a[2], c[2]; double la[2], lc[2];
+        others(t, u, v, a, la); others(t, v, u, c, lc);
+        double t0 = t->len[u][k], Lc, L[3], T[3];
+        eng_sumtable(e, t, u, v, sc);
+        (void)eng_newton_branch(e, t0, &Lc);
+        for (int alt = 1; alt <= 2; alt++) {
+            int y = (alt == 1) ? 0 : 1;
+            side sa = eng_side(e, t, a[0], u), sb = eng_side(e, t, a[1], u), sy = eng_side(e, t, c[y], v), sz = eng_side(e, t, c[1 - y], v);
+            nv_core(e, sa, sy, la[0], lc[y], X, xs);          /* new u: (a0, swapped-in child) */
+            nv_core(e, sb, sz, la[1], lc[1 - y], Y, ys);      /* new v: (a1, remaining child)  */
+            side SX = {X, xs, 0}, SY = {Y, ys, 0};
+            sumtable_core(e, SX, SY, sc);
+            T[alt] = eng_newton_branch(e, t0, &L[alt]);
+            /* scaling constants differ between configurations: compare full lnL */
+            { double corr = 0; for (int p = 0; p < np; p++) corr += e->a->weight[p] * sc[p]; L[alt] -= corr * PO_LOG_2_256; }
+        }
+        { int *s0 = (int *)malloc(sizeof(int) * np); eng_sumtable(e, t, u, v, s0); double corr = 0; for (int p = 0; p < np; p++) corr += e->a->weight[p] * s0[p]; Lc -= corr * PO_LOG_2_256; free(s0); }
+        int best = (L[2] > L[1]) ? 2 : 1;
+        double gain = L[best] - Lc;
+        if (gain > NNI_MIN_GAIN) { cands[ncand].u = u; cands[ncand].v = v; cands[ncand].alt = best; cands[ncand].gain = gain; cands[ncand].t = T[best]; cands[ncand].order = ncand; ncand++; }
+    }
+    free(X); free(Y); free(xs); free(ys); free(sc);
+    int applied = 0;
+    if (ncand > 0) {
+        qsort(cands, ncand, sizeof(nni_cand), cand_cmp);
+        char *used = (char *)calloc(t->nnodes, 1);
+        po_tree *backup = po_tree_copy(t);
+        double lnl0 = *lnl;
+        for (i = 0; i < ncand; i++) {
+            if (used[cands[i].u] || used[cands[i].v]) continue;
+            used[cands[i].u] = used[cands[i].v] = 1;
+            nni_apply(t, cands[i].u, cands[i].v, cands[i].alt, cands[i].t); applied++;
+        }
+        eng_invalidate_all(e);
+        double l1 = light_smooth(e, t);
+        if (!(l1 > lnl0 + 1e-6)) {                     /* combined moves did not help: best one only */
+            tree_assign(t, backup); eng_invalidate_all(e);
+            nni_apply(t, cands[0].u, cands[0].v, cands[0].alt, cands[0].t); applied = 1;
+            l1 = light_smooth(e, t);
+            if (!(l1 > lnl0 + 1e-6)) { tree_assign(t, backup); eng_invalidate_all(e); applied = 0; l1 = lnl0; }
+        }
+        *lnl = l1;
+        po_tree_free(backup); free(used);
+    }
+    free(cands);
+    return applied;
+}
+
+double po_engine_search(po_engine *e, po_tree **t_inout, int spr_radius, double eps) {
+    if (!*t_inout) *t_inout = po_nj_tree(e->a);
+    po_tree *t = *t_inout;
+    (void)spr_radius;
+    eng_bind(e, t);
+    double lnl = po_engine_optimize(e, t, 1, 0.1);
+    for (int outer = 0; outer < 20; outer++) {
+        int moves = 0;
+        for (int round = 0; round < 100; round++) { int m = nni_round(e, t, &lnl); if (!m) break; moves += m; }
+        lnl = po_engine_optimize(e, t, 1, 0.1);
+        if (!moves) break;
+    }
+    return po_engine_optimize(e, t, 1, eps);
 }

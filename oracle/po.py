@@ -59,11 +59,10 @@ def lib():
         L.po_engine_branch_derivs.argtypes = [vp, vp, C.c_int, C.c_int, dp, dp, dp]
         L.po_bruteforce_lnl.restype = C.c_double
         L.po_bruteforce_lnl.argtypes = [vp, vp, C.c_int, C.c_double, vp]
-        if hasattr(L, "po_engine_search"):
-            L.po_engine_search.restype = C.c_double
-            L.po_engine_search.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_double]
-            L.po_nj_tree.restype = vp
-            L.po_nj_tree.argtypes = [vp]
+        L.po_engine_search.restype = C.c_double
+        L.po_engine_search.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_double]
+        L.po_nj_tree.restype = vp
+        L.po_nj_tree.argtypes = [vp]
         L.free = C.CDLL(None).free
         L.free.argtypes = [vp]
         _LIB = L
@@ -194,9 +193,8 @@ class Engine:
         return a.value, b.value, c.value
 
     def search(self, start=None, spr_radius=0, eps=1e-3):
-        p = C.c_void_p(start.copy().ptr.value if start is not None else None)
-        if start is not None:
-            start = None
+        """NJ start (or a copy of `start`), NNI hill climbing; returns (lnL, Tree)."""
+        p = C.c_void_p(lib().po_tree_copy(start.ptr) if start is not None else None)
         lnl = lib().po_engine_search(self.ptr, C.byref(p), spr_radius, eps)
         return lnl, Tree(aln=self.aln, ptr=p.value)
 
@@ -205,6 +203,10 @@ class Engine:
             lib().po_engine_free(self.ptr)
         except Exception:
             pass
+
+
+def nj_tree(aln):
+    return Tree(aln=aln, ptr=lib().po_nj_tree(aln.ptr))
 
 
 def bruteforce_lnl(aln, model, tree, ncat=4, alpha=1.0):

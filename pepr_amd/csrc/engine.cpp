@@ -118,8 +118,8 @@ int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *con
         off[g] = total;
         total += align_up((size_t)nt * mp, 256);                       // codes
         total += align_up((size_t)mp * 8, 256);                        // weight
-        total += (size_t)G.slot_cap * CLV_ROWS * mp * 8;               // clv
-        total += align_up((size_t)G.slot_cap * mp * 4, 256);           // scalers
+        total += (size_t)(G.slot_cap + NSCRATCH) * CLV_ROWS * mp * 8;  // clv (+ scratch)
+        total += align_up((size_t)(G.slot_cap + NSCRATCH) * mp * 4, 256);   // scalers
         total += (size_t)CLV_ROWS * mp * 8;                            // sumtable
         total += align_up((size_t)mp * 4, 256);                        // sumtable scalers
         total += align_up((size_t)mp * 8, 256);                        // per-pattern lnL
@@ -135,8 +135,8 @@ int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *con
         char *p = arena + off[g];
         G.d_codes = (uint8_t *)p; p += align_up((size_t)nt * mp, 256);
         G.d_weight = (double *)p; p += align_up((size_t)mp * 8, 256);
-        G.d_clv = (double *)p; p += (size_t)G.slot_cap * CLV_ROWS * mp * 8;
-        G.d_scl = (int *)p; p += align_up((size_t)G.slot_cap * mp * 4, 256);
+        G.d_clv = (double *)p; p += (size_t)(G.slot_cap + NSCRATCH) * CLV_ROWS * mp * 8;
+        G.d_scl = (int *)p; p += align_up((size_t)(G.slot_cap + NSCRATCH) * mp * 4, 256);
         G.d_sumtab = (double *)p; p += (size_t)CLV_ROWS * mp * 8;
         G.d_sumscl = (int *)p; p += align_up((size_t)mp * 4, 256);
         G.d_patlnl = (double *)p;
@@ -223,6 +223,12 @@ int Batch::slot_for(Gene &G, int idx) {
 // ------------------------------------------------------------------------------------------
 // lazy collection of the newviews a message depends on
 // ------------------------------------------------------------------------------------------
+Side Batch::msg(int g, int node, int toward) const {
+    const Gene &G = genes[g];
+    if (node < G.aln.ntax) return {SIDE_TIP, node};
+    return {SIDE_MSG, (node - G.aln.ntax) * 3 + G.tree.slot(node, toward)};
+}
+
 int Batch::need(int g, int v, int to, std::vector<PendingOp> &ops) {
     Gene &G = genes[g];
     const int nt = G.aln.ntax;
@@ -251,8 +257,8 @@ int Batch::need(int g, int v, int to, std::vector<PendingOp> &ops) {
             continue;
         }
         const int lvl = std::max(f.lv[0], f.lv[1]) + 1;
-        PendingOp op; op.gene = g; op.idx = idx; op.level = lvl; ci = 0;
-        for (int q = 0; q < 3; ++q) if (q != f.k) { op.child[ci] = G.tree.nbr[f.v][q]; op.t[ci] = G.tree.len[f.v][q]; ci++; }
+        PendingOp op; op.gene = g; op.out_kind = SIDE_MSG; op.out_id = idx; op.level = lvl; ci = 0;
+        for (int q = 0; q < 3; ++q) if (q != f.k) { op.child[ci] = msg(g, G.tree.nbr[f.v][q], f.v); op.t[ci] = G.tree.len[f.v][q]; ci++; }
         ops.push_back(op);
         G.pend_level[idx] = lvl;
         ret = lvl;
@@ -294,11 +300,10 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     NewtonReq *hnewt = (NewtonReq *)(hs + o_newt);
     const double *eig = ctx->d_eigfrags[pi_mode];
 
-    auto side = [&](Gene &G, int node, int toward, const void *&ptr, const int *&scl, bool &tip) {
-        const int nt = G.aln.ntax, mp = G.aln.mpad;
-        if (node < nt) { ptr = G.d_codes + (size_t)node * mp; scl = nullptr; tip = true; return 0; }
-        const int idx = (node - nt) * 3 + G.tree.slot(node, toward);
-        const int s = G.slot_of[idx];
+    auto side = [&](Gene &G, const Side &sd, const void *&ptr, const int *&scl, bool &tip) {
+        const int mp = G.aln.mpad;
+        if (sd.kind == SIDE_TIP) { ptr = G.d_codes + (size_t)sd.id * mp; scl = nullptr; tip = true; return 0; }
+        const int s = sd.kind == SIDE_MSG ? G.slot_of[sd.id] : G.slot_cap + sd.id;
         if (s < 0) return -1;
         ptr = G.d_clv + (size_t)s * CLV_ROWS * mp; scl = G.d_scl + (size_t)s * mp; tip = false;
         return 0;
@@ -317,14 +322,13 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         const bool has_ops = iop < nops && ops[iop].gene == (int)g;
         if (!has_ops && tail_of[g] < 0) continue;
         Gene &G = genes[g];
-        const int nt = G.aln.ntax, mp = G.aln.mpad;
+        const int mp = G.aln.mpad;
         GeneRun &run = hruns[nruns++];
         run.op_begin = (int)nout;
         max_mpad = std::max(max_mpad, mp);
         for (; iop < nops && ops[iop].gene == (int)g; ++iop) {
             PendingOp &o = ops[iop];
-            const int v = nt + o.idx / 3;
-            const int s = slot_for(G, o.idx);
+            const int s = o.out_kind == SIDE_MSG ? slot_for(G, o.out_id) : G.slot_cap + o.out_id;
             if (s < 0) return ctx->fail(-4, "CLV slots exhausted (score-only batch used for a multi-root request)");
             NvOp &d = hops[nout++];
             std::memset(&d, 0, sizeof d);
@@ -332,7 +336,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             d.out = G.d_clv + (size_t)s * CLV_ROWS * mp;
             d.out_scl = G.d_scl + (size_t)s * mp;
             bool lt, rt;
-            if (side(G, o.child[0], v, d.left, d.l_scl, lt) || side(G, o.child[1], v, d.right, d.r_scl, rt))
+            if (side(G, o.child[0], d.left, d.l_scl, lt) || side(G, o.child[1], d.right, d.r_scl, rt))
                 return ctx->fail(-5, "internal: child message has no slot");
             d.flags = (lt ? 1 : 0) | (rt ? 2 : 0);
             d.mpad = mp;
@@ -348,7 +352,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             NvOp &d = hops[nout++];
             std::memset(&d, 0, sizeof d);
             bool lt, rt;
-            if (side(G, t.u, t.v, d.left, d.l_scl, lt) || side(G, t.v, t.u, d.right, d.r_scl, rt))
+            if (side(G, t.a, d.left, d.l_scl, lt) || side(G, t.b, d.right, d.r_scl, rt))
                 return ctx->fail(-5, "internal: tail message has no slot");
             d.flags = (lt ? 1 : 0) | (rt ? 2 : 0); d.mpad = mp; d.mode = t.mode;
             if (t.mode == MODE_EVALUATE) {
@@ -405,7 +409,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     ctx->stats[K_HOST_BUILD].launches++; ctx->stats[K_HOST_BUILD].ms += t_launched - t_begin;
     ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += t_done - t_launched;
     ctx->resolve_events();
-    for (auto &o : ops) { Gene &G = genes[o.gene]; G.valid[o.idx] = 1; G.pend_level[o.idx] = -1; }
+    for (auto &o : ops) if (o.out_kind == SIDE_MSG) { Gene &G = genes[o.gene]; G.valid[o.out_id] = 1; G.pend_level[o.out_id] = -1; }
     return 0;
 }
 
@@ -419,7 +423,7 @@ int Batch::evaluate(const std::vector<char> &active, double *lnl) {
         Gene &G = genes[g];
         const int r = G.tree.nbr[0][0];
         need(g, r, 0, ops);
-        tails.push_back({g, 0, r, MODE_EVALUATE, G.tree.len[0][0], 0});
+        tails.push_back({g, msg(g, 0, r), msg(g, r, 0), MODE_EVALUATE, G.tree.len[0][0], 0});
     }
     if (int rc = run(ops, tails)) return rc;
     for (auto &t : tails) lnl[t.gene] = h_scalars[8 * t.gene];
@@ -445,7 +449,7 @@ int Batch::root_derivs(double *lnl, double *d1, double *d2) {
         Gene &G = genes[g];
         const int r = G.tree.nbr[0][0];
         need(g, r, 0, ops);
-        tails.push_back({g, 0, r, MODE_SUMTABLE, G.tree.len[0][0], 0});
+        tails.push_back({g, msg(g, 0, r), msg(g, r, 0), MODE_SUMTABLE, G.tree.len[0][0], 0});
     }
     if (int rc = run(ops, tails)) return rc;
     for (int g = 0; g < (int)genes.size(); ++g) { lnl[g] = h_scalars[8 * g + 1]; d1[g] = h_scalars[8 * g + 2]; d2[g] = h_scalars[8 * g + 3]; }
@@ -482,14 +486,15 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
             if (!active[g] || step >= order[g].size()) continue;
             auto [v, w] = order[g][step];
             need(g, v, w, ops); need(g, w, v, ops);
-            tails.push_back({g, v, w, MODE_SUMTABLE, genes[g].tree.len[v][genes[g].tree.slot(v, w)], 32});
+            tails.push_back({g, msg(g, v, w), msg(g, w, v), MODE_SUMTABLE, genes[g].tree.len[v][genes[g].tree.slot(v, w)], 32});
         }
         if (int rc = run(ops, tails)) return rc;
         for (auto &t : tails) {
             Gene &G = genes[t.gene];
+            auto [v, w] = order[t.gene][step];
             const double nl = h_scalars[8 * t.gene], old = t.t0;
             maxdelta[t.gene] = std::max(maxdelta[t.gene], std::fabs(nl - old));
-            if (nl != old) { G.tree.set_len(t.u, t.v, nl); branch_changed(t.gene, t.u, t.v); }
+            if (nl != old) { G.tree.set_len(v, w, nl); branch_changed(t.gene, v, w); }
         }
     }
     return 0;
@@ -517,14 +522,17 @@ int Batch::opt_alpha(const std::vector<char> &active, double *lnl) {
     return 0;
 }
 
-int Batch::optimize(bool opt_alpha_flag, double eps, double *lnl) {
+int Batch::optimize(bool opt_alpha_flag, double eps, double *lnl, const std::vector<char> *mask) {
     const int n = (int)genes.size();
+    std::vector<char> active(n, 1);
+    if (mask) active = *mask;
     for (int g = 0; g < n; ++g) {
+        if (!active[g]) continue;
         Tree &T = genes[g].tree;
         for (auto &l : T.len) for (double &x : l) if (x < TMIN) x = TMIN;
         invalidate_all(g);
     }
-    std::vector<char> active(n, 1);
+    const std::vector<char> initial(active);
     std::vector<double> cur(n), nl(n), md;
     if (int rc = evaluate(active, cur.data())) return rc;
     for (int round = 0; round < 100; ++round) {
@@ -545,7 +553,7 @@ int Batch::optimize(bool opt_alpha_flag, double eps, double *lnl) {
             if (gain < eps) active[g] = 0;
         }
     }
-    for (int g = 0; g < n; ++g) lnl[g] = cur[g];
+    for (int g = 0; g < n; ++g) if (initial[g]) lnl[g] = cur[g];
     return 0;
 }
 

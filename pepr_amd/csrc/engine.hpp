@@ -59,7 +59,10 @@ struct Gene {
 
 struct pml_alignment_view { int ntax, nsites; const char *const *names; const char *const *rows; };
 
-struct PendingOp { int gene, idx, level; int child[2]; double t[2]; };
+constexpr int NSCRATCH = 4;          // extra CLV slots per gene for candidate evaluation (NNI / SPR)
+enum { SIDE_TIP = 0, SIDE_MSG = 1, SIDE_SCRATCH = 2 };
+struct Side { int kind, id; };       // tip node id | directed-edge index (v-ntax)*3+k | scratch slot
+struct PendingOp { int gene, out_kind, out_id, level; Side child[2]; double t[2]; };
 
 struct Batch {
     Ctx *ctx = nullptr;
@@ -86,13 +89,16 @@ struct Batch {
     int root_derivs(double *lnl, double *d1, double *d2);
     int smooth_pass(const std::vector<char> &active, std::vector<double> &maxdelta);
     int opt_alpha(const std::vector<char> &active, double *lnl);
-    int optimize(bool opt_alpha_flag, double eps, double *lnl);
+    int optimize(bool opt_alpha_flag, double eps, double *lnl, const std::vector<char> *mask = nullptr);
+    int light_smooth(const std::vector<char> &active, double *lnl);
+    int nni_round(const std::vector<char> &active, std::vector<double> &lnl, std::vector<int> &applied);
     int search(bool nni, int spr_radius, bool opt_alpha_flag, double eps, double *lnl);
 
     // --- plumbing ---
     int need(int g, int v, int to, std::vector<PendingOp> &ops);   // returns level
     // run the collected newviews, then the tail ops (evaluate or sumtable+newton), one sync
-    struct Tail { int gene, u, v; int mode; double t0; int max_iter; };
+    struct Tail { int gene; Side a, b; int mode; double t0; int max_iter; };
+    Side msg(int g, int node, int toward) const;
     int run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails);
     int ensure_stage(size_t bytes);
     int ensure_frags(size_t sets);

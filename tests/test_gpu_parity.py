@@ -190,3 +190,35 @@ def test_full_size_properties_c3(gpu_ctx):
         assert abs(out[g]["lnl"] - l1[g]) < 1e-8 * abs(l1[g])
     dup = [(G[0][0], [r + r for r in G[0][1]])]
     assert abs(gpu_ctx.score(dup, NW[:1], alpha=0.8)[0]["lnl"] - 2 * l1[0]) < 1e-8 * abs(l1[0])
+
+
+def test_nj_start_tree_matches_oracle(gpu_ctx, oracle_lib):
+    """Both sides build the same NJ start tree (DESIGN.md 'Start tree')."""
+    from pepr_amd import engine
+    for i, (nt, ns) in enumerate([(6, 80), (15, 200), (40, 300)]):
+        names, rows, _ = synth.simulate_alignment(nt, ns, 400 + i, missing_frac=0.1)
+        a = oracle_lib.Alignment(names, rows)
+        ref = oracle_lib.nj_tree(a)
+        b = engine.Batch(gpu_ctx, [(names, rows)], None, alpha=1.0)
+        got = oracle_lib.Tree(b.newick(0, 12), a)
+        assert got.rf(ref) == 0 and abs(got.length() - ref.length()) < 1e-9
+        b.close()
+
+
+def test_search_vs_oracle(gpu_ctx, oracle_lib):
+    """NJ start + NNI hill climbing: same topology (RF = 0), |dlnL| < 1e-3, same alpha --
+    the north star's acceptance numbers, against the oracle's search."""
+    po = oracle_lib
+    genes, refs = [], []
+    for i, (nt, ns) in enumerate([(10, 300), (20, 400), (14, 250), (30, 300)]):
+        names, rows, nw = synth.simulate_alignment(nt, ns, 500 + i, missing_frac=0.1 * (i % 2))
+        genes.append((names, rows))
+        a = po.Alignment(names, rows); e = po.Engine(a, po.Model(0), 4, 1.0)
+        lnl, tree = e.search(None, 0, 1e-3)
+        refs.append((a, tree, lnl, e.alpha, po.Tree(nw, a)))
+    out = gpu_ctx.search(genes, None, alpha=1.0, nni=True, spr_radius=0, epsilon=1e-3)
+    for r, (a, tree, lnl, alpha, true) in zip(out, refs):
+        got = po.Tree(r["newick"], a)
+        assert got.rf(tree) == 0
+        assert abs(r["lnl"] - lnl) < 1e-3 and abs(r["alpha"] - alpha) < 1e-3 * max(1.0, alpha)
+        assert got.rf(true) <= tree.rf(true)
