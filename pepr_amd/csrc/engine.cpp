@@ -158,6 +158,8 @@ void Batch::destroy() {
     if (d_stage) hipFree(d_stage);
     if (d_frags) hipFree(d_frags);
     if (d_scalars) hipFree(d_scalars);
+    if (d_nsync) hipFree(d_nsync);
+    d_nsync = nullptr;
     if (h_scalars) hipHostFree(h_scalars);
     arena = nullptr; h_stage = d_stage = nullptr; d_frags = nullptr; d_scalars = h_scalars = nullptr;
 }
@@ -284,6 +286,13 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     for (auto &t : tails) { if (t.mode == MODE_EVALUATE) neval++; else nnewton++; }
     const size_t nreq = 2 * nops + neval;
     if (int rc = ensure_frags(std::max(nreq, (size_t)1))) return rc;
+    if (nnewton > nsync_cap) {
+        if (d_nsync) hipFree(d_nsync);
+        d_nsync = nullptr; nsync_cap = 0;
+        const size_t cap = std::max(nnewton * 2, (size_t)256);
+        HIPCHK(hipMalloc((void **)&d_nsync, cap * NEWTON_SYNC_DOUBLES * sizeof(double)));
+        nsync_cap = cap;
+    }
     const size_t ngenes = genes.size();
     const size_t o_req = 0;
     const size_t o_ops = align_up(o_req + nreq * sizeof(PmatReq), 256);
@@ -316,7 +325,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         tail_of[tails[i].gene] = (int)i;
     }
     size_t nout = 0, nruns = 0, ie = 0, in = 0, ireq = 0, iop = 0;
-    int max_mpad = 0;
+    int max_mpad = 0, newton_maxm = 0;
     double algo_bytes = 0;
     for (size_t g = 0; g < ngenes; ++g) {
         const bool has_ops = iop < nops && ops[iop].gene == (int)g;
@@ -366,11 +375,13 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             } else {
                 d.pl = eig; d.pr = eig + PFRAG;
                 d.out = G.d_sumtab; d.out_scl = G.d_sumscl;
-                NewtonReq &nr = hnewt[in++];
+                NewtonReq &nr = hnewt[in];
                 nr.sumtab = G.d_sumtab; nr.weight = G.d_weight; nr.scl = G.d_sumscl;
                 std::memcpy(nr.rates, G.rates, sizeof nr.rates);
                 nr.t0 = t.t0; nr.out = d_scalars + 8 * g; nr.mpad = mp; nr.max_iter = t.max_iter;
+                nr.sync = d_nsync + (size_t)in * NEWTON_SYNC_DOUBLES; newton_maxm = std::max(newton_maxm, mp);
                 algo_bytes += (double)G.aln.npat * ((lt ? 1 : 640) + (rt ? 1 : 640) + 640);
+                in++;
             }
         }
         run.op_end = (int)nout;
@@ -396,8 +407,9 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     if (nnewton) {
         double nb = 0;
         for (auto &t : tails) if (t.mode != MODE_EVALUATE) nb += (double)genes[t.gene].aln.npat * 640;
+        HIPCHK(hipMemsetAsync(d_nsync, 0, nnewton * NEWTON_SYNC_DOUBLES * sizeof(double), ctx->stream));
         ctx->tic(K_NEWTON, nb);
-        launch_newton(md, (const NewtonReq *)(ds + o_newt), (int)nnewton, ctx->stream);
+        launch_newton(md, (const NewtonReq *)(ds + o_newt), (int)nnewton, newton_maxm, ctx->stream);
         ctx->toc();
     }
     if (!tails.empty())

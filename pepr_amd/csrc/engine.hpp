@@ -74,6 +74,7 @@ struct Batch {
     void *d_stage = nullptr; size_t d_cap = 0;
     double *d_frags = nullptr; size_t frag_cap = 0;      // in fragment sets
     double *d_scalars = nullptr; double *h_scalars = nullptr;   // 8 doubles per gene
+    double *d_nsync = nullptr; size_t nsync_cap = 0;             // Newton inter-workgroup sync blocks
 
     int create(Ctx *c, int n, const pml_alignment_view *alns, const char *const *newicks,
                int pi_mode, int ncat, double alpha, bool score_only);

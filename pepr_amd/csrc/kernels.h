@@ -65,9 +65,12 @@ struct NewtonReq {          // Newton-Raphson on one branch from its sumtable
     double rates[NCAT];
     double t0;
     double *out;            // out[0]=t, out[1]=lnL, out[2]=d1, out[3]=d2 (at returned t)
+    double *sync;           // NEWTON_SYNC_DOUBLES zeroed doubles: arrival counter + per-workgroup partial sums
     int mpad;
     int max_iter;           // 0: derivatives at t0 only
 };
+constexpr int NEWTON_MAX_SPLIT = 8;
+constexpr int NEWTON_SYNC_DOUBLES = 2 + 2 * NEWTON_MAX_SPLIT * 3 + 14;   // 64 doubles = 512 B
 
 enum { MODE_NEWVIEW = 0, MODE_SUMTABLE = 1, MODE_EVALUATE = 2 };
 
@@ -77,6 +80,6 @@ void launch_pmat(const ModelDev *model, const PmatReq *reqs, double *frags, int 
 void launch_eigfrags(const ModelDev *model, double *frags2, hipStream_t s);
 void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, hipStream_t s);
 void launch_reduce(const ReduceReq *reqs, int n, hipStream_t s);
-void launch_newton(const ModelDev *model, const NewtonReq *reqs, int n, hipStream_t s);
+void launch_newton(const ModelDev *model, const NewtonReq *reqs, int n, int max_mpad, hipStream_t s);
 
 }  // namespace pml

@@ -290,21 +290,26 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : 3) void k_oplist(
 }
 
 // ------------------------------------------------------------------------------------------
-// deterministic block reduction (fixed order: wave shuffle tree, then waves 0..3 in order)
+// deterministic block reduction (fixed order: wave shuffle tree, then waves in index order)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
     return v;
 }
-template <int N>
-__device__ __forceinline__ void block_sum(double (&v)[N], double (*red)[4]) {
+template <int N, int WAVES>
+__device__ __forceinline__ void block_sum(double (&v)[N], double (*red)[WAVES]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < N; ++i) { const double s = wave_sum(v[i]); if (lane == 0) red[i][wave] = s; }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = ((red[i][0] + red[i][1]) + red[i][2]) + red[i][3];
+    for (int i = 0; i < N; ++i) {
+        double s = red[i][0];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) s += red[i][w];
+        v[i] = s;
+    }
     __syncthreads();
 }
 
@@ -316,25 +321,50 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceReq *__restrict__ re
         const double w = r.weight[p];
         if (w != 0.0) acc[0] += w * r.patlnl[p];
     }
-    block_sum<1>(acc, red);
+    block_sum<1, 4>(acc, red);
     if (threadIdx.x == 0) *r.out = acc[0];
 }
 
 // ------------------------------------------------------------------------------------------
 // k_newton: Newton-Raphson on one branch length from its eigen-basis sumtable (RAxML "makenewz",
-// SURVEY 8a-11 v).  One workgroup per (gene, branch); the whole iteration runs on the device.
-// Control flow is the oracle's eng_newton_branch(), evaluated redundantly by every thread.
+// SURVEY 8a-11 v).  The whole iteration runs on the device.  A single CU streams the 640 B/pattern
+// sumtable at only ~70 GB/s (one CU's L2 rate), so a request is SPLIT over S workgroups (pattern
+// slices) that exchange three partial sums per evaluation through global memory:
+//   producer: sc1 (agent-scope relaxed atomic) stores of the partials -> s_waitcnt vmcnt(0) ->
+//             agent-scope atomic add on the arrival counter;
+//   consumer: sc1 poll of the counter -> sc1 loads of all S partials, summed in slice order
+//             (bit-reproducible) -> LDS broadcast + workgroup barrier.
+// (cdna_hip_programming.md Guideline 16, "every load sc1" form.)  All S x n workgroups of a launch
+// are co-resident (launch_newton caps the grid), every workgroup of a request executes the same
+// evaluations because they all see identical sums, and the spin is bounded.
+// Control flow is the oracle's eng_newton_branch().
 // ------------------------------------------------------------------------------------------
 #define PML_TMIN 1.0e-6
 #define PML_TMAX 34.5
 
+__device__ __forceinline__ void st_agent(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
 __global__ __launch_bounds__(256) void k_newton(const ModelDev *__restrict__ md,
-                                                const NewtonReq *__restrict__ reqs) {
+                                                const NewtonReq *__restrict__ reqs, int S) {
     __shared__ double ex[3][NCAT * NS];
     __shared__ double red[3][4];
-    const NewtonReq r = reqs[blockIdx.x];
-    const int tid = threadIdx.x, mpad = r.mpad;
+    __shared__ double bc[4];
+    const NewtonReq r = reqs[blockIdx.y];
+    const int tid = threadIdx.x, mpad = r.mpad, wg = blockIdx.x;
     const size_t M = (size_t)mpad;
+    const int slice = ((mpad / 32 + S - 1) / S) * 32;
+    const int p_begin = wg * slice, p_end = min(mpad, p_begin + slice);
+    unsigned *cnt = reinterpret_cast<unsigned *>(r.sync);
+    double *part = r.sync + 2;
+    int nevals = 0;
+    bool failed = false;
 
     auto eval_at = [&](double t, double &L, double &d1, double &d2) {
         if (tid < NCAT * NS) {
@@ -344,11 +374,11 @@ __global__ __launch_bounds__(256) void k_newton(const ModelDev *__restrict__ md,
         }
         __syncthreads();
         double acc[3] = {0.0, 0.0, 0.0};
-        for (int p = tid; p < mpad; p += 256) {
+        for (int p = p_begin + tid; p < p_end; p += 256) {
             const double w = r.weight[p];
             if (w == 0.0) continue;
             double f = 0.0, f1 = 0.0, f2 = 0.0;
-#pragma unroll 8
+#pragma unroll 16
             for (int row = 0; row < CLV_ROWS; ++row) {
                 const double x = r.sumtab[(size_t)row * M + p];
                 f += x * ex[0][row]; f1 += x * ex[1][row]; f2 += x * ex[2][row];
@@ -358,30 +388,58 @@ __global__ __launch_bounds__(256) void k_newton(const ModelDev *__restrict__ md,
             acc[1] += w * r1;
             acc[2] += w * (f2 / f - r1 * r1);
         }
-        block_sum<3>(acc, red);
+        block_sum<3, 4>(acc, red);
+        if (S > 1) {
+            if (tid == 0) {
+                double *mine = part + ((nevals & 1) * NEWTON_MAX_SPLIT + wg) * 3;
+                st_agent(mine, acc[0]); st_agent(mine + 1, acc[1]); st_agent(mine + 2, acc[2]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned target = (unsigned)S * (unsigned)(nevals + 1);
+                long spins = 0;
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > 20000000L) { bc[3] = 1.0; break; }      // bounded: never hang the GPU
+                }
+                double tot[3] = {0.0, 0.0, 0.0};
+                const double *base = part + (nevals & 1) * NEWTON_MAX_SPLIT * 3;
+                for (int w = 0; w < S; ++w) { tot[0] += ld_agent(base + w * 3); tot[1] += ld_agent(base + w * 3 + 1); tot[2] += ld_agent(base + w * 3 + 2); }
+                bc[0] = tot[0]; bc[1] = tot[1]; bc[2] = tot[2];
+            }
+            __syncthreads();
+            acc[0] = bc[0]; acc[1] = bc[1]; acc[2] = bc[2];
+            if (bc[3] != 0.0) failed = true;
+            __syncthreads();
+        }
+        ++nevals;
         L = acc[0]; d1 = acc[1]; d2 = acc[2];
     };
 
+    if (tid == 0) bc[3] = 0.0;
+    __syncthreads();
     double t = r.t0;
     if (r.max_iter > 0) t = t < PML_TMIN ? PML_TMIN : (t > PML_TMAX ? PML_TMAX : t);
     double L, d1, d2;
     eval_at(t, L, d1, d2);
-    for (int it = 0; it < r.max_iter; ++it) {
+    for (int it = 0; it < r.max_iter && !failed; ++it) {
         const double step = (d2 < 0.0) ? -d1 / d2 : (d1 > 0.0 ? t : -0.5 * t);
         double tn = t + step, Ln, n1, n2;
         int bt = 0;
         for (;;) {
             tn = tn < PML_TMIN ? PML_TMIN : (tn > PML_TMAX ? PML_TMAX : tn);
             eval_at(tn, Ln, n1, n2);
-            if (Ln >= L - 1e-9 || bt >= 8) break;
+            if (failed || Ln >= L - 1e-9 || bt >= 8) break;
             ++bt; tn = 0.5 * (tn + t);
         }
-        if (Ln < L - 1e-9) break;
+        if (failed || Ln < L - 1e-9) break;
         const double dt = fabs(tn - t);
         t = tn; L = Ln; d1 = n1; d2 = n2;
         if (dt < 1e-8) break;
     }
-    if (tid == 0) { r.out[0] = t; r.out[1] = L; r.out[2] = d1; r.out[3] = d2; }
+    if (tid == 0 && wg == 0) {
+        if (failed) { t = r.t0; L = __builtin_nan(""); }
+        r.out[0] = t; r.out[1] = L; r.out[2] = d1; r.out[3] = d2;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -414,9 +472,15 @@ void launch_reduce(const ReduceReq *reqs, int n, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_reduce, dim3(n), dim3(256), 0, s, reqs);
 }
-void launch_newton(const ModelDev *model, const NewtonReq *reqs, int n, hipStream_t s) {
+void launch_newton(const ModelDev *model, const NewtonReq *reqs, int n, int max_mpad, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_newton, dim3(n), dim3(256), 0, s, model, reqs);
+    int S = max_mpad / 256;
+    S = S < 1 ? 1 : (S > NEWTON_MAX_SPLIT ? NEWTON_MAX_SPLIT : S);
+    const int chunk = 1024 / S;          // S * chunk workgroups of 256 threads are co-resident on 256 CUs
+    for (int off = 0; off < n; off += chunk) {
+        const int m = (n - off < chunk) ? n - off : chunk;
+        hipLaunchKernelGGL(k_newton, dim3(S, m), dim3(256), 0, s, model, reqs + off, S);
+    }
 }
 
 }  // namespace pml
