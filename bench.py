@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=["c3", "c4", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-search", action="store_true", help="skip the gene-trees/s leg (NJ + NNI search of every gene)")
     args = ap.parse_args()
 
     import numpy as np
@@ -102,10 +103,37 @@ def main():
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt, tot_pat = float(tmax[0]), float(tsum[1])
 
+    # second metric of BASELINE.json: complete tree inferences per second (NJ start, model
+    # optimisation, NNI hill climbing), every gene of the shard, one batched call
+    search = None
+    if not args.no_search:
+        sb = engine.Batch(ctx, [(g[0], g[1]) for g in genes], None, alpha=1.0)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        slnl, salpha = sb.search(True, True, 0, 1e-3)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        sdt = time.perf_counter() - ts
+        rf = [engine.rf_distance(genes[i][2], sb.newick(i)) for i in range(len(genes))]
+        sb.close()
+        if world > 1:
+            t = torch.tensor([sdt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX); sdt = float(t[0])
+        search = {"gene_trees_per_sec": per_gpu * world / sdt, "seconds": sdt, "genes": per_gpu * world,
+                  "algorithm": "NJ start + WAG+G4 model optimisation + NNI hill climbing (eps 1e-3)",
+                  "rf_to_generating_tree_mean_rank0": float(np.mean(rf)), "finite": bool(np.all(np.isfinite(slnl)))}
+
     if rank == 0:
         nv = stats["newview"]
         avg_ms = nv["ms"] / max(nv["launches"], 1)
         achieved = nv["algo_bytes"] / max(nv["launches"], 1) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.workload)
+        if os.path.exists(pmc):       # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
+            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
         out = {
             "metric": "M site-lnL/sec (WAG+G4 full-tree likelihood evaluations x alignment patterns)",
             "value": tot_pat * args.steps / dt / 1e6, "unit": "M site-lnL/s",
@@ -116,10 +144,12 @@ def main():
                 args.workload, per_gpu, ntax, nsites), "patterns_per_gpu": npat, "genes_total": per_gpu * world,
                 "parallelism": "gene-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_oplist (newview+evaluate)", "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "algo_bytes_per_launch": nv["algo_bytes"] / max(nv["launches"], 1)},
             "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in stats.items() if v["launches"]},
         }
+        if search is not None:
+            out["search"] = search
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(genes[:2], alpha)
         print(json.dumps(out), flush=True)
