@@ -940,15 +940,133 @@ static int nni_round(po_engine *e, po_tree *t, double *lnl) {
     return applied;
 }
 
+/* ---- lazy SPR (spec mirrored by pepr_amd/csrc/search.cpp) ------------------------------------
+ * For every inner node p and neighbour s (ascending): prune the subtree hanging off p through s
+ * (p's other neighbours x,y get joined by one branch tx+ty) and try every edge within `radius`
+ * edges of the pruning point: insert p in its middle (halves of the branch), keep the pendant
+ * length, score WITHOUT re-optimisation.  The best candidate is applied if it beats the current
+ * lnL by > 0.01; then the four touched branches are Newton-optimised ((p,s), (p,g), (p,h), (x,y))
+ * and the move is kept only if the tree really improved.  Path messages of the pruned tree live
+ * in one temporary CLV per depth. */
+#define SPR_MIN_GAIN 0.01
+#define SPR_MAX_RADIUS 6
+typedef struct {
+    po_engine *e; po_tree *t; int p, s, x, y, radius;
+    side S; double ts;
+    double *pm[SPR_MAX_RADIUS + 1]; int *ps[SPR_MAX_RADIUS + 1];   /* path message per depth */
+    double *ins; int *insc;
+    double best; int bg, bh;
+} spr_ctx;
+
+static double spr_score(spr_ctx *c, side Mgh, int g, int h) {
+    po_engine *e = c->e; const po_tree *t = c->t;
+    int K = e->K, np = e->npat;
+    double tgh = t->len[g][slot_of(t, g, h)];
+    side Hg = eng_side(e, t, h, g);
+    nv_core(e, Mgh, Hg, 0.5 * tgh, 0.5 * tgh, c->ins, c->insc);
+    /* evaluate across the pendant branch: A = S (subtree), B = insertion CLV */
+    double (*P)[PO_NS][PO_NS] = (double (*)[PO_NS][PO_NS])malloc(sizeof(double[PO_NS][PO_NS]) * K);
+    eng_pmats(e, c->ts, P);
+    double total = 0;
+    for (int p = 0; p < np; p++) {
+        double site = 0;
+        for (int k = 0; k < K; k++) {
+            const double *xa = c->S.clv ? c->S.clv + ((size_t)p * K + k) * 20 : e->tipvec[c->S.codes[p]];
+            const double *xb = c->ins + ((size_t)p * K + k) * 20;
+            double cat = 0;
+            for (int s2 = 0; s2 < 20; s2++) { double yv = 0; for (int j = 0; j < 20; j++) yv += P[k][s2][j] * xb[j]; cat += e->m->pi[s2] * xa[s2] * yv; }
+            site += cat;
+        }
+        site /= K;
+        int sc = (c->S.scl ? c->S.scl[p] : 0) + c->insc[p];
+        total += e->a->weight[p] * (log(site) - sc * PO_LOG_2_256);
+    }
+    free(P); e->n_evaluate++;
+    return total;
+}
+/* candidate edge (g,h) reached with path message Mgh (message from g towards h in the pruned tree) */
+static void spr_explore(spr_ctx *c, int g, int h, int depth, side Mgh) {
+    const po_tree *t = c->t; po_engine *e = c->e;
+    double sc = spr_score(c, Mgh, g, h);
+    if (sc > c->best) { c->best = sc; c->bg = g; c->bh = h; }
+    if (h < e->ntax || depth >= c->radius) return;
+    int ch[2]; double lc[2]; others(t, h, g, ch, lc);
+    double tgh = t->len[g][slot_of(t, g, h)];
+    for (int i = 0; i < 2; i++) {
+        /* message from h towards ch[i]: combines Mgh (over the full branch g-h) and the other child */
+        side O = eng_side(e, t, ch[1 - i], h);
+        nv_core(e, Mgh, O, tgh, lc[1 - i], c->pm[depth], c->ps[depth]);
+        side M = {c->pm[depth], c->ps[depth], 0};
+        spr_explore(c, h, ch[i], depth + 1, M);
+    }
+}
+static void spr_apply(po_tree *t, int p, int x, int y, int g, int h) {
+    int kx = slot_of(t, p, x), ky = slot_of(t, p, y);
+    double tx = t->len[p][kx], ty = t->len[p][ky], tgh = t->len[g][slot_of(t, g, h)];
+    /* join x-y */
+    int sx = slot_of(t, x, p), sy = slot_of(t, y, p);
+    t->nbr[x][sx] = y; t->len[x][sx] = tx + ty; t->nbr[y][sy] = x; t->len[y][sy] = tx + ty;
+    /* insert p into (g,h) */
+    int sg = slot_of(t, g, h), sh = slot_of(t, h, g);
+    t->nbr[g][sg] = p; t->len[g][sg] = 0.5 * tgh; t->nbr[h][sh] = p; t->len[h][sh] = 0.5 * tgh;
+    t->nbr[p][kx] = g; t->len[p][kx] = 0.5 * tgh; t->nbr[p][ky] = h; t->len[p][ky] = 0.5 * tgh;
+}
+static void newton_edge(po_engine *e, po_tree *t, int u, int v) {
+    eng_sumtable(e, t, u, v, NULL);
+    double old = t->len[u][slot_of(t, u, v)], nl = eng_newton_branch(e, old, NULL);
+    if (nl != old) { tree_set_len(t, u, v, nl); eng_branch_changed(e, t, u, v); }
+}
+static int spr_round(po_engine *e, po_tree *t, int radius, double *lnl) {
+    int n = e->ntax, np = e->npat, K = e->K, moves = 0;
+    if (radius > SPR_MAX_RADIUS) radius = SPR_MAX_RADIUS;
+    if (n < 5) return 0;
+    spr_ctx c; memset(&c, 0, sizeof c); c.e = e; c.t = t; c.radius = radius;
+    for (int d = 0; d <= SPR_MAX_RADIUS; d++) { c.pm[d] = (double *)malloc(sizeof(double) * (size_t)np * K * 20); c.ps[d] = (int *)malloc(sizeof(int) * np); }
+    c.ins = (double *)malloc(sizeof(double) * (size_t)np * K * 20); c.insc = (int *)malloc(sizeof(int) * np);
+    for (int p = n; p < t->nnodes; p++) for (int ks = 0; ks < 3; ks++) {
+        int s = t->nbr[p][ks], xy[2]; double lxy[2];
+        others(t, p, s, xy, lxy);
+        int x = xy[0], y = xy[1]; double tx = lxy[0], ty = lxy[1];
+        c.p = p; c.s = s; c.x = x; c.y = y; c.ts = t->len[p][ks];
+        c.S = eng_side(e, t, s, p);
+        c.best = -1e300; c.bg = c.bh = -1;
+        /* side of x: pruned-tree message from x to each child = f(message y->p over tx+ty, other child) */
+        for (int sidei = 0; sidei < 2; sidei++) {
+            int a = sidei == 0 ? x : y, b = sidei == 0 ? y : x;      /* explore into a's side; b is across */
+            if (a < n) continue;
+            side B = eng_side(e, t, b, p);
+            int ch[2]; double lc[2]; others(t, a, p, ch, lc);
+            for (int i = 0; i < 2; i++) {
+                side O = eng_side(e, t, ch[1 - i], a);
+                nv_core(e, B, O, tx + ty, lc[1 - i], c.pm[0], c.ps[0]);
+                side M = {c.pm[0], c.ps[0], 0};
+                spr_explore(&c, a, ch[i], 1, M);
+            }
+        }
+        if (c.bg < 0 || !(c.best > *lnl + SPR_MIN_GAIN)) continue;
+        po_tree *backup = po_tree_copy(t);
+        spr_apply(t, p, x, y, c.bg, c.bh);
+        eng_invalidate_all(e);
+        newton_edge(e, t, p, s); newton_edge(e, t, p, c.bg); newton_edge(e, t, p, c.bh); newton_edge(e, t, x, y);
+        double l1 = po_engine_lnl(e, t, NULL);
+        if (l1 > *lnl + 1e-6) { *lnl = l1; moves++; }
+        else { tree_assign(t, backup); eng_invalidate_all(e); }
+        po_tree_free(backup);
+    }
+    for (int d = 0; d <= SPR_MAX_RADIUS; d++) { free(c.pm[d]); free(c.ps[d]); }
+    free(c.ins); free(c.insc);
+    return moves;
+}
+
 double po_engine_search(po_engine *e, po_tree **t_inout, int spr_radius, double eps) {
     if (!*t_inout) *t_inout = po_nj_tree(e->a);
     po_tree *t = *t_inout;
-    (void)spr_radius;
     eng_bind(e, t);
     double lnl = po_engine_optimize(e, t, 1, 0.1);
     for (int outer = 0; outer < 20; outer++) {
         int moves = 0;
         for (int round = 0; round < 100; round++) { int m = nni_round(e, t, &lnl); if (!m) break; moves += m; }
+        if (spr_radius > 0) for (int round = 0; round < 10; round++) { int m = spr_round(e, t, spr_radius, &lnl); if (!m) break; moves += m; }
         lnl = po_engine_optimize(e, t, 1, 0.1);
         if (!moves) break;
     }

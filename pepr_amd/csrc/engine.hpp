@@ -59,7 +59,7 @@ struct Gene {
 
 struct pml_alignment_view { int ntax, nsites; const char *const *names; const char *const *rows; };
 
-constexpr int NSCRATCH = 4;          // extra CLV slots per gene for candidate evaluation (NNI / SPR)
+constexpr int NSCRATCH = 8;          // extra CLV slots per gene for candidate evaluation (NNI / SPR)
 enum { SIDE_TIP = 0, SIDE_MSG = 1, SIDE_SCRATCH = 2 };
 struct Side { int kind, id; };       // tip node id | directed-edge index (v-ntax)*3+k | scratch slot
 struct PendingOp { int gene, out_kind, out_id, level; Side child[2]; double t[2]; };
@@ -93,6 +93,7 @@ struct Batch {
     int optimize(bool opt_alpha_flag, double eps, double *lnl, const std::vector<char> *mask = nullptr);
     int light_smooth(const std::vector<char> &active, double *lnl);
     int nni_round(const std::vector<char> &active, std::vector<double> &lnl, std::vector<int> &applied);
+    int spr_round(const std::vector<char> &active, int radius, std::vector<double> &lnl, std::vector<int> &moves);
     int search(bool nni, int spr_radius, bool opt_alpha_flag, double eps, double *lnl);
 
     // --- plumbing ---

@@ -13,6 +13,7 @@
 // node, re-optimise lightly (<= 2 smoothing passes), fall back to the single best move if the
 // combination did not improve, and to no move if that fails too.
 #include <algorithm>
+#include <functional>
 
 #include "engine.hpp"
 
@@ -144,12 +145,169 @@ int Batch::nni_round(const std::vector<char> &active, std::vector<double> &lnl, 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// lazy SPR round (oracle: spr_round / spr_explore / spr_score).  Per gene a small state machine
+// walks (prune node p, neighbour s) in order; every candidate regraft edge is ONE run() unit:
+// [path message of the pruned tree for this depth] + insertion CLV + evaluate across the pendant
+// branch.  Genes advance in lockstep, each on its own tree.
+// ------------------------------------------------------------------------------------------
+namespace {
+constexpr double SPR_MIN_GAIN = 0.01;
+constexpr int SPR_MAX_RADIUS = 6;
+constexpr int SPR_INS_SLOT = 7;
+struct PathOp { int depth; Side left; double tl; Side right; double tr; };
+struct Unit { std::vector<PathOp> paths; int g, h, mslot; };   // score candidate edge (g,h) with path slot mslot
+struct SprState {
+    int p = 0, ks = 0; bool done = false;
+    int s = 0, x = 0, y = 0; double tx = 0, ty = 0, ts = 0;
+    std::vector<Unit> units; size_t ui = 0;
+    double best = -1e300; int bg = -1, bh = -1;
+    int phase = 0;
+    Tree backup;
+};
+void spr_apply(Tree &T, int p, int x, int y, int g, int h) {
+    const int kx = T.slot(p, x), ky = T.slot(p, y);
+    const double tx = T.len[p][kx], ty = T.len[p][ky], tgh = T.len[g][T.slot(g, h)];
+    const int sx = T.slot(x, p), sy = T.slot(y, p);
+    T.nbr[x][sx] = y; T.len[x][sx] = tx + ty; T.nbr[y][sy] = x; T.len[y][sy] = tx + ty;
+    const int sg = T.slot(g, h), sh = T.slot(h, g);
+    T.nbr[g][sg] = p; T.len[g][sg] = 0.5 * tgh; T.nbr[h][sh] = p; T.len[h][sh] = 0.5 * tgh;
+    T.nbr[p][kx] = g; T.len[p][kx] = 0.5 * tgh; T.nbr[p][ky] = h; T.len[p][ky] = 0.5 * tgh;
+}
+}  // namespace
+
+int Batch::spr_round(const std::vector<char> &active, int radius, std::vector<double> &lnl, std::vector<int> &moves) {
+    const int n = (int)genes.size();
+    moves.assign(n, 0);
+    radius = std::min(radius, SPR_MAX_RADIUS);
+    std::vector<SprState> st(n);
+    for (int g = 0; g < n; ++g) { st[g].done = !active[g] || genes[g].aln.ntax < 5; st[g].p = genes[g].aln.ntax; st[g].ks = 0; st[g].phase = -1; }
+
+    // builds the unit list of the prune (p, ks) of gene g (DFS order of the oracle's recursion)
+    auto start_prune = [&](int g) {
+        SprState &S = st[g]; const Tree &T = genes[g].tree; const int nt = T.ntax;
+        S.s = T.nbr[S.p][S.ks];
+        int xy[2]; double lxy[2]; others(T, S.p, S.s, xy, lxy);
+        S.x = xy[0]; S.y = xy[1]; S.tx = lxy[0]; S.ty = lxy[1]; S.ts = T.len[S.p][S.ks];
+        S.units.clear(); S.ui = 0; S.best = -1e300; S.bg = S.bh = -1; S.phase = 0;
+        std::vector<PathOp> pending;
+        std::function<void(int, int, int)> explore = [&](int gg, int h, int depth) {
+            Unit u; u.paths = pending; pending.clear(); u.g = gg; u.h = h; u.mslot = depth - 1;
+            S.units.push_back(u);
+            if (h < nt || depth >= radius) return;
+            int ch[2]; double lc[2]; others(T, h, gg, ch, lc);
+            const double tgh = T.len[gg][T.slot(gg, h)];
+            for (int i = 0; i < 2; ++i) {
+                pending.push_back({depth, {SIDE_SCRATCH, depth - 1}, tgh, msg(g, ch[1 - i], h), lc[1 - i]});
+                explore(h, ch[i], depth + 1);
+            }
+        };
+        for (int sidei = 0; sidei < 2; ++sidei) {
+            const int a = sidei == 0 ? S.x : S.y, b = sidei == 0 ? S.y : S.x;
+            if (a < nt) continue;
+            int ch[2]; double lc[2]; others(T, a, S.p, ch, lc);
+            for (int i = 0; i < 2; ++i) {
+                pending.push_back({0, msg(g, b, S.p), S.tx + S.ty, msg(g, ch[1 - i], a), lc[1 - i]});
+                explore(a, ch[i], 1);
+            }
+        }
+    };
+    auto advance_cursor = [&](int g) {
+        SprState &S = st[g];
+        S.phase = -1;
+        if (++S.ks == 3) { S.ks = 0; ++S.p; }
+        if (S.p >= genes[g].tree.nnodes()) S.done = true;
+    };
+    auto need_side = [&](int g, const Side &sd, std::vector<PendingOp> &ops) {
+        if (sd.kind != SIDE_MSG) return;
+        const Gene &G = genes[g];
+        const int v = G.aln.ntax + sd.id / 3, to = G.tree.nbr[v][sd.id % 3];
+        need(g, v, to, ops);
+    };
+
+    for (;;) {
+        std::vector<PendingOp> ops; std::vector<Tail> tails;
+        std::vector<int> kind(n, -1);       // what each gene submitted: 0 score, 1..4 newton, 5 evaluate
+        bool any = false;
+        for (int g = 0; g < n; ++g) {
+            SprState &S = st[g];
+            if (S.done) continue;
+            // find next prune with at least one candidate
+            while (!S.done && S.phase < 0) {
+                start_prune(g);
+                if (S.units.empty()) advance_cursor(g);
+            }
+            if (S.done) continue;
+            any = true;
+            const Tree &T = genes[g].tree;
+            if (S.phase == 0) {
+                const Unit &u = S.units[S.ui];
+                for (const PathOp &po : u.paths) {
+                    need_side(g, po.left, ops); need_side(g, po.right, ops);
+                    PendingOp o; o.gene = g; o.out_kind = SIDE_SCRATCH; o.out_id = po.depth; o.level = 0;
+                    o.child[0] = po.left; o.t[0] = po.tl; o.child[1] = po.right; o.t[1] = po.tr;
+                    ops.push_back(o);
+                }
+                const double tgh = T.len[u.g][T.slot(u.g, u.h)];
+                const Side hg = msg(g, u.h, u.g), sp = msg(g, S.s, S.p);
+                need_side(g, hg, ops); need_side(g, sp, ops);
+                PendingOp I; I.gene = g; I.out_kind = SIDE_SCRATCH; I.out_id = SPR_INS_SLOT; I.level = 0;
+                I.child[0] = {SIDE_SCRATCH, u.mslot}; I.t[0] = 0.5 * tgh; I.child[1] = hg; I.t[1] = 0.5 * tgh;
+                ops.push_back(I);
+                tails.push_back({g, sp, {SIDE_SCRATCH, SPR_INS_SLOT}, MODE_EVALUATE, S.ts, 0});
+                kind[g] = 0;
+            } else if (S.phase >= 1 && S.phase <= 4) {
+                int u, v;
+                if (S.phase == 1) { u = S.p; v = S.s; } else if (S.phase == 2) { u = S.p; v = S.bg; }
+                else if (S.phase == 3) { u = S.p; v = S.bh; } else { u = S.x; v = S.y; }
+                need(g, u, v, ops); need(g, v, u, ops);
+                tails.push_back({g, msg(g, u, v), msg(g, v, u), MODE_SUMTABLE, T.len[u][T.slot(u, v)], 32});
+                kind[g] = S.phase;
+            } else {
+                const int r = T.nbr[0][0];
+                need(g, r, 0, ops);
+                tails.push_back({g, msg(g, 0, r), msg(g, r, 0), MODE_EVALUATE, T.len[0][0], 0});
+                kind[g] = 5;
+            }
+        }
+        if (!any) break;
+        if (int rc = run(ops, tails)) return rc;
+        for (int g = 0; g < n; ++g) {
+            if (kind[g] < 0) continue;
+            SprState &S = st[g]; Tree &T = genes[g].tree;
+            const double r0 = h_scalars[8 * g];
+            if (kind[g] == 0) {
+                const Unit &u = S.units[S.ui];
+                if (r0 > S.best) { S.best = r0; S.bg = u.g; S.bh = u.h; }
+                if (++S.ui < S.units.size()) continue;
+                if (S.bg >= 0 && S.best > lnl[g] + SPR_MIN_GAIN) {
+                    S.backup = T;
+                    spr_apply(T, S.p, S.x, S.y, S.bg, S.bh);
+                    invalidate_all(g);
+                    S.phase = 1;
+                } else advance_cursor(g);
+            } else if (kind[g] <= 4) {
+                int u, v;
+                if (kind[g] == 1) { u = S.p; v = S.s; } else if (kind[g] == 2) { u = S.p; v = S.bg; }
+                else if (kind[g] == 3) { u = S.p; v = S.bh; } else { u = S.x; v = S.y; }
+                const double old = T.len[u][T.slot(u, v)];
+                if (r0 != old) { T.set_len(u, v, r0); branch_changed(g, u, v); }
+                S.phase = kind[g] + 1;
+            } else {
+                if (r0 > lnl[g] + 1e-6) { lnl[g] = r0; moves[g]++; }
+                else { T = S.backup; invalidate_all(g); }
+                advance_cursor(g);
+            }
+        }
+    }
+    return 0;
+}
+
 int Batch::search(bool nni, int spr_radius, bool opt_alpha_flag, double eps, double *lnl_out) {
-    (void)spr_radius;
     const int n = (int)genes.size();
     std::vector<double> lnl(n, 0.0);
     if (int rc = optimize(opt_alpha_flag, 0.1, lnl.data())) return rc;
-    std::vector<char> active(n, nni ? 1 : 0);
+    std::vector<char> active(n, (nni || spr_radius > 0) ? 1 : 0);
     for (int outer = 0; outer < 20; ++outer) {
         bool any = false; for (char a : active) any |= a;
         if (!any) break;
@@ -160,6 +318,16 @@ int Batch::search(bool nni, int spr_radius, bool opt_alpha_flag, double eps, dou
             if (!anyr) break;
             if (int rc = nni_round(ract, lnl, applied)) return rc;
             for (int g = 0; g < n; ++g) if (ract[g]) { if (applied[g] == 0) ract[g] = 0; else moves[g] += applied[g]; }
+        }
+        if (spr_radius > 0) {
+            std::vector<char> sact(active);
+            std::vector<int> smoves;
+            for (int round = 0; round < 10; ++round) {
+                bool anys = false; for (char a : sact) anys |= a;
+                if (!anys) break;
+                if (int rc = spr_round(sact, spr_radius, lnl, smoves)) return rc;
+                for (int g = 0; g < n; ++g) if (sact[g]) { if (smoves[g] == 0) sact[g] = 0; else moves[g] += smoves[g]; }
+            }
         }
         if (int rc = optimize(opt_alpha_flag, 0.1, lnl.data(), &active)) return rc;
         for (int g = 0; g < n; ++g) if (active[g] && moves[g] == 0) active[g] = 0;

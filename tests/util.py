@@ -86,3 +86,35 @@ def numpy_lnl(names, rows, newick, alpha, pi_mode="raxml", ncat=4):
     cv, ls = rec(tree)
     site = np.log((cv * pi[None, None, :]).sum(2).mean(0)) + ls
     return site.sum(), site
+
+
+def splits(newick):
+    """dict {frozenset(smaller-side taxa) -> branch length} over the internal edges of a tree."""
+    tree = parse_newick(newick)
+    allt = []
+
+    def leaves(nd):
+        if not nd[0]:
+            return [nd[1]]
+        return sum((leaves(k) for k in nd[0]), [])
+    allt = frozenset(leaves(tree))
+    out = {}
+
+    def rec(nd, top):
+        if not nd[0]:
+            return frozenset([nd[1]])
+        s = frozenset().union(*[rec(k, False) for k in nd[0]])
+        if not top and 1 < len(s) < len(allt) - 1:
+            key = s if (len(s) * 2 < len(allt) or (len(s) * 2 == len(allt) and min(allt) in s)) else allt - s
+            out[key] = out.get(key, 0.0) + nd[2]
+        return s
+    rec(tree, True)
+    return out
+
+
+def rf_collapsed(nw_a, nw_b, min_len=1e-5):
+    """Robinson-Foulds distance that ignores internal branches of (near) zero length: a split only
+    counts as a difference if it is supported by a branch longer than min_len in its own tree."""
+    a, b = splits(nw_a), splits(nw_b)
+    d = sum(1 for s, l in a.items() if l > min_len and s not in b) + sum(1 for s, l in b.items() if l > min_len and s not in a)
+    return d
