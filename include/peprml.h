@@ -14,6 +14,8 @@
  *   pml_*_batch    <- .../pepr/tree/pipeline/PhylogenomicPipeline2.java:1587-1633
  *                        GeneSubsetTreeRunnable.run(): the data-parallel loop of independent tree builds
  *   pml_rf_distance<- .../pepr/tree/AdvancedTree.java:1460-1491 (Robinson-Foulds used for acceptance)
+ *   pml_support_tree<- .../pepr/tree/TreeSupportDecorator.java:86-163 addSupportValues(): integer
+ *                        bipartition counts of the support trees written as node labels of the main tree
  *
  * Conventions: caller owns inputs (nothing is retained after return);
  * the library allocates results, the caller releases them with pml_result_free(); no files, no
@@ -128,6 +130,9 @@ void pml_free(void *p);
 
 /* tree utilities (host) */
 int pml_rf_distance(const char *newick_a, const char *newick_b, int *rf_out);
+/* main tree with, on every internal branch, the number of support trees containing its bipartition
+ * as an integer node label `)87:0.1`; *out is freed with pml_free */
+int pml_support_tree(const char *main_newick, int ntrees, const char *const *support_newicks, int digits, char **out);
 
 /* profiling: HIP-event time of device kernels since the last reset (cfg.profile = 1) */
 enum { PML_K_PMAT = 0, PML_K_NEWVIEW = 1, PML_K_EVALUATE = 2, PML_K_SUMTABLE = 3, PML_K_NEWTON = 4,

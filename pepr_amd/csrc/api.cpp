@@ -243,6 +243,20 @@ int pml_rf_distance(const char *a, const char *b, int *rf) {
     return PML_OK;
 }
 
+int pml_support_tree(const char *main_newick, int ntrees, const char *const *support, int digits, char **out) {
+    if (!main_newick || !out || ntrees < 0 || (ntrees > 0 && !support)) return PML_EINVAL;
+    *out = nullptr;
+    try {
+        std::vector<std::string> names; Tree main; std::string err;
+        if (!Tree::parse_free(main_newick, names, main, err)) { g_err = err; return PML_EPARSE; }
+        std::vector<Tree> others((size_t)ntrees);
+        for (int i = 0; i < ntrees; ++i)
+            if (!support[i] || !Tree::parse(support[i], names, others[i], err)) { g_err = "support tree " + std::to_string(i) + ": " + err; return PML_EPARSE; }
+        *out = dup_string(main.newick_labeled(names, digits, support_counts(main, others)));
+    } catch (const std::exception &e) { g_err = e.what(); return PML_EINVAL; }
+    return *out ? PML_OK : PML_ENOMEM;
+}
+
 int pml_kernel_stats(pml_ctx *ctx, int k, long long *launches, double *ms, double *bytes) {
     if (!ctx || k < 0 || k >= K_COUNT) return PML_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->c.mu);

@@ -338,6 +338,58 @@ std::string Tree::newick(const std::vector<std::string> &names, int digits) cons
     return out;
 }
 
+// bipartition of the edge (from -> v): bitset of the taxa below v, canonicalised to the side
+// that does not contain taxon 0
+static void collect_splits(const Tree &t, std::vector<std::vector<uint64_t>> &out, std::vector<std::pair<int, int>> *edges) {
+    const int n = t.ntax, words = (n + 63) / 64;
+    std::function<std::vector<uint64_t>(int, int)> rec = [&](int v, int from) {
+        std::vector<uint64_t> s(words, 0);
+        if (v < n) { s[v >> 6] |= 1ULL << (v & 63); return s; }
+        for (int k = 0; k < 3; ++k) { const int w = t.nbr[v][k]; if (w < 0 || w == from) continue; auto c = rec(w, v); for (int i = 0; i < words; ++i) s[i] |= c[i]; }
+        if (from >= n) { out.push_back(s); if (edges) edges->push_back({from, v}); }
+        return s;
+    };
+    const int r = t.nbr[0][0];
+    for (int k = 0; k < 3; ++k) { const int w = t.nbr[r][k]; if (w < 0 || w == 0) continue; rec(w, r); }
+}
+
+std::vector<std::vector<int>> support_counts(const Tree &main, const std::vector<Tree> &others) {
+    std::vector<std::vector<uint64_t>> ms; std::vector<std::pair<int, int>> edges;
+    collect_splits(main, ms, &edges);
+    std::vector<std::vector<int>> counts(main.nnodes(), std::vector<int>(3, -1));
+    std::vector<int> c(ms.size(), 0);
+    for (const Tree &o : others) {
+        std::vector<std::vector<uint64_t>> os; collect_splits(o, os, nullptr);
+        std::sort(os.begin(), os.end());
+        for (size_t i = 0; i < ms.size(); ++i) if (std::binary_search(os.begin(), os.end(), ms[i])) c[i]++;
+    }
+    for (size_t i = 0; i < ms.size(); ++i) {
+        const int u = edges[i].first, v = edges[i].second;
+        counts[u][main.slot(u, v)] = c[i]; counts[v][main.slot(v, u)] = c[i];
+    }
+    return counts;
+}
+
+std::string Tree::newick_labeled(const std::vector<std::string> &names, int digits, const std::vector<std::vector<int>> &lab) const {
+    std::string out; char buf[64];
+    std::function<void(int, int, double)> rec = [&](int v, int from, double l) {
+        if (v < ntax) out += names[v];
+        else {
+            out += '('; bool first = true;
+            for (int k = 0; k < 3; ++k) { const int w = nbr[v][k]; if (w < 0 || w == from) continue; if (!first) out += ','; first = false; rec(w, v, len[v][k]); }
+            out += ')';
+            const int c = lab[v][slot(v, from)];
+            if (c >= 0) out += std::to_string(c);
+        }
+        std::snprintf(buf, sizeof buf, ":%.*f", digits, l); out += buf;
+    };
+    const int r = nbr[0][0];
+    out += '('; out += names[0]; std::snprintf(buf, sizeof buf, ":%.*f", digits, len[0][0]); out += buf;
+    for (int k = 0; k < 3; ++k) { const int w = nbr[r][k]; if (w < 0 || w == 0) continue; out += ','; rec(w, r, len[r][k]); }
+    out += ");";
+    return out;
+}
+
 int rf_distance(const Tree &a, const Tree &b) {
     const int n = a.ntax, words = (n + 63) / 64;
     auto splits = [&](const Tree &t) {

@@ -39,9 +39,14 @@ struct Tree {
     // parse without an alignment: tips numbered in order of appearance, names returned
     static bool parse_free(const char *newick, std::vector<std::string> &names, Tree &out, std::string &err);
     std::string newick(const std::vector<std::string> &names, int digits) const;
+    // labels[v] (v >= ntax) is printed after the ')' of inner node v when >= 0 (support values);
+    // the label belongs to the branch between v and its parent in the printed orientation
+    std::string newick_labeled(const std::vector<std::string> &names, int digits, const std::vector<std::vector<int>> &edge_label) const;
 };
 
 int rf_distance(const Tree &a, const Tree &b);    // (|A|+|B|-2|A&B|)/2 over non-trivial splits
+// counts[u][k] = number of `others` containing the bipartition of main's internal edge (u, nbr[u][k]); -1 elsewhere
+std::vector<std::vector<int>> support_counts(const Tree &main, const std::vector<Tree> &others);
 
 struct EncodedAlignment {
     int ntax = 0, nsites = 0, npat = 0, mpad = 0;

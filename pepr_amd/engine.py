@@ -193,3 +193,17 @@ def rf_distance(newick_a, newick_b):
     if rc:
         raise PmlError(rc, L.pml_last_error(None).decode())
     return rf.value
+
+
+def support_tree(main_newick, support_newicks, digits=6):
+    """Main tree decorated with integer bipartition counts (TreeSupportDecorator.addSupportValues)."""
+    L = _lib.load()
+    n = len(support_newicks)
+    arr = (C.c_char_p * max(n, 1))(*[s.encode() for s in support_newicks]) if n else None
+    p = C.c_void_p()
+    rc = L.pml_support_tree(main_newick.encode(), n, arr, digits, C.byref(p))
+    if rc:
+        raise PmlError(rc, L.pml_last_error(None).decode())
+    s = C.string_at(p).decode()
+    L.pml_free(p)
+    return s

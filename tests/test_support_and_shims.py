@@ -1,0 +1,58 @@
+"""Support decoration (TreeSupportDecorator.java:86-163 semantics) and the CLI shims' argument
+handling -- no GPU needed.  The shims' numeric paths are covered by tests/test_gpu_shims.py."""
+import os
+import subprocess
+
+import pytest
+
+from pepr_amd import engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FT = os.path.join(ROOT, "bin", "FastTree_WAG")
+RX = os.path.join(ROOT, "bin", "raxmlHPC")
+
+
+def test_support_counts():
+    main = "((a:1,b:1):0.5,(c:1,d:1):0.4,(e:1,f:1):0.3);"
+    sup = ["((a:1,b:1):1,(c:1,d:1):1,(e:1,f:1):1);", "((a:1,c:1):1,(b:1,d:1):1,(e:1,f:1):1);",
+           "(a:1,(b:1,(c:1,(d:1,(e:1,f:1):1):1):1):1);"]
+    out = engine.support_tree(main, sup, 2)
+    assert out == "(a:1.00,b:1.00,((c:1.00,d:1.00)1:0.40,(e:1.00,f:1.00)3:0.30)2:0.50);"
+    assert engine.rf_distance(out, main) == 0                  # labels are parsed back as supports
+    assert engine.support_tree(main, [], 2).count(")0:") == 3
+    # every support tree identical to the main tree -> all counts = number of trees (README:19-20:
+    # "100% support for all branches")
+    full = engine.support_tree(main, [main] * 100, 3)
+    assert full.count(")100:") == 3
+    with pytest.raises(engine.PmlError):
+        engine.support_tree(main, ["((a:1,b:1):1,(c:1,x:1):1,(e:1,f:1):1);"])
+
+
+def test_shims_exist_and_reject_bad_usage(tmp_path):
+    for exe in (FT, RX, RX + "-PTHREADS"):
+        assert os.access(exe, os.X_OK), exe
+    def run(args):
+        return subprocess.run(args, cwd=tmp_path, capture_output=True, text=True)
+    r = run([FT, "-gamma", "-nosupport", "missing.faa"])
+    assert r.returncode != 0 and "cannot open" in r.stderr and r.stdout == ""
+    r = run([FT, "-gtr", "-nt", "x.faa"])
+    assert r.returncode != 0 and "nucleotide" in r.stderr
+    r = run([RX, "-f", "d", "-m", "PROTGAMMAWAG", "-s", "x.phy", "-n", "r1", "-y"])
+    assert r.returncode != 0 and "parsimony" in r.stderr
+    r = run([RX, "-f", "d", "-m", "GTRGAMMA", "-s", "x.phy", "-n", "r1"])
+    assert r.returncode != 0 and "WAG" in r.stderr
+    (tmp_path / "RAxML_info.r2").write_text("old run\n")          # RAxML refuses a used run name (RAxMLRunner.java:518-532)
+    r = run([RX, "-f", "d", "-m", "PROTGAMMAWAG", "-s", "x.phy", "-n", "r2"])
+    assert r.returncode != 0 and "already exist" in r.stderr
+    (tmp_path / "bad.phy").write_text("3 5\na AAAAA\nb AAAA\n")
+    r = run([RX, "-f", "d", "-m", "PROTGAMMAWAG", "-s", "bad.phy", "-n", "r3"])
+    assert r.returncode != 0
+
+
+def test_shim_fails_loudly_without_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    (tmp_path / "a.faa").write_text(">a\nARND\n>b\nARNE\n>c\nAQND\n>d\nGRND\n")
+    r = subprocess.run([FT, "-gamma", "-nosupport", "a.faa"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode != 0 and "HIP device" in r.stderr and r.stdout == ""
