@@ -14,6 +14,10 @@
  *   pml_*_batch    <- .../pepr/tree/pipeline/PhylogenomicPipeline2.java:1587-1633
  *                        GeneSubsetTreeRunnable.run(): the data-parallel loop of independent tree builds
  *   pml_rf_distance<- .../pepr/tree/AdvancedTree.java:1460-1491 (Robinson-Foulds used for acceptance)
+ *   pml_jackknife  <- .../pepr/tree/pipeline/PhylogenomicPipeline2.java:994-1126
+ *                        buildConcatenatedTreeWithGeneWiseJackKnifeSupport(): full tree + N support trees on
+ *                        random gene subsets (:959-977, 1227-1275, 1587-1633) + support counts, ONE call
+ *   pml_concatenate<- .../pepr/alignment/MSAConcatenator.java:78-189 (sorted taxon union, '?' padding)
  *   pml_support_tree<- .../pepr/tree/TreeSupportDecorator.java:86-163 addSupportValues(): integer
  *                        bipartition counts of the support trees written as node labels of the main tree
  *
@@ -133,6 +137,28 @@ int pml_rf_distance(const char *newick_a, const char *newick_b, int *rf_out);
 /* main tree with, on every internal branch, the number of support trees containing its bipartition
  * as an integer node label `)87:0.1`; *out is freed with pml_free */
 int pml_support_tree(const char *main_newick, int ntrees, const char *const *support_newicks, int digits, char **out);
+
+/* gene-wise jackknife (the data-parallel loop of the reference, one call):
+ *   full tree  = search on the concatenation of ALL genes (NNI + SPR radius spr_radius_full),
+ *   supports   = `reps` searches (NJ + NNI), each on the concatenation of `subset_size` genes drawn
+ *                without replacement (0 = ngenes/2, PhylogenomicPipeline2.java:1599-1617),
+ *   result     = full tree whose internal branches carry the number of support trees containing them.
+ * Genes may cover different taxon subsets: the concatenation uses the sorted union of taxon names
+ * and pads absent genes with '?' (MSAConcatenator.java:118-120,164-170).  The reference draws the
+ * subsets from an unseeded java.util.Random; here the draw is seeded (deterministic). */
+typedef struct {
+    int reps;                    /* support trees (PEPR default 100) */
+    int subset_size;             /* genes per replicate; 0 = ngenes / 2 */
+    unsigned long long seed;
+    int spr_radius_full;         /* SPR radius for the full tree (0 = NNI only) */
+    double epsilon;              /* search epsilon (0 = 1e-3) */
+} pml_jackknife_opts;
+int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *genes, const pml_model *model,
+                  const pml_jackknife_opts *opts, pml_result *main_out /* newick carries the supports */,
+                  char **support_newicks_out /* optional: reps lines, '\n'-separated; pml_free */);
+/* host-only: FASTA text (">taxon\nSEQ\n" per taxon, SequenceAlignment.java:405-416) of the
+ * concatenation of the selected genes (sel == NULL: all), taxa = sorted union, '?' padding */
+int pml_concatenate(int ngenes, const pml_alignment *genes, int nsel, const int *sel, char **fasta_out);
 
 /* profiling: HIP-event time of device kernels since the last reset (cfg.profile = 1) */
 enum { PML_K_PMAT = 0, PML_K_NEWVIEW = 1, PML_K_EVALUATE = 2, PML_K_SUMTABLE = 3, PML_K_NEWTON = 4,

@@ -9,7 +9,7 @@
 
 using namespace pml;
 
-struct pml_ctx { Ctx c; };
+struct pml_ctx { Ctx c; };     // (same definition in jackknife.cpp)
 struct pml_batch { Batch b; pml_ctx *owner; };
 
 static thread_local std::string g_err;

@@ -1,0 +1,145 @@
+// jackknife.cpp -- gene-wise jackknife driver: the reference's data-parallel loop
+// (PhylogenomicPipeline2.java:994-1126, 1227-1275, 1587-1633) as one native call.
+// Concatenation follows MSAConcatenator.concatenate (MSAConcatenator.java:78-189): taxa = sorted
+// union of the genes' taxon names, a gene that lacks a taxon contributes '?' columns.
+// Replicates are built in memory (no FASTA files, no per-replicate text parsing) and searched as
+// ONE device batch; the support counting is TreeSupportDecorator.addSupportValues (:86-163).
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <random>
+#include <set>
+
+#include "../../include/peprml.h"
+#include "engine.hpp"
+
+using namespace pml;
+
+struct pml_ctx { Ctx c; };
+
+namespace {
+struct Concat { std::vector<std::string> names, rows; };
+
+bool concatenate(int ngenes, const pml_alignment *genes, const std::vector<int> &sel, Concat &out, std::string &err) {
+    std::set<std::string> uni;
+    for (int g : sel) {
+        if (g < 0 || g >= ngenes) { err = "gene index out of range"; return false; }
+        const pml_alignment &A = genes[g];
+        if (!A.names || !A.rows || A.ntax <= 0) { err = "bad alignment"; return false; }
+        for (int i = 0; i < A.ntax; ++i) uni.insert(A.names[i]);
+    }
+    out.names.assign(uni.begin(), uni.end());           // std::set order == Arrays.sort for ASCII names
+    out.rows.assign(out.names.size(), std::string());
+    for (int g : sel) {
+        const pml_alignment &A = genes[g];
+        std::map<std::string, int> idx;
+        for (int i = 0; i < A.ntax; ++i) idx[A.names[i]] = i;
+        for (size_t t = 0; t < out.names.size(); ++t) {
+            auto it = idx.find(out.names[t]);
+            if (it == idx.end()) out.rows[t].append((size_t)A.nsites, '?');
+            else {
+                if ((int)strnlen(A.rows[it->second], (size_t)A.nsites) < A.nsites) { err = "row shorter than nsites"; return false; }
+                out.rows[t].append(A.rows[it->second], (size_t)A.nsites);
+            }
+        }
+    }
+    return true;
+}
+char *dup_cstr(const std::string &s) { char *p = (char *)std::malloc(s.size() + 1); if (p) std::memcpy(p, s.c_str(), s.size() + 1); return p; }
+}  // namespace
+
+extern "C" int pml_concatenate(int ngenes, const pml_alignment *genes, int nsel, const int *sel, char **fasta_out) {
+    if (!genes || ngenes <= 0 || !fasta_out) return PML_EINVAL;
+    *fasta_out = nullptr;
+    try {
+        std::vector<int> s;
+        if (sel) s.assign(sel, sel + nsel); else { s.resize(ngenes); for (int i = 0; i < ngenes; ++i) s[i] = i; }
+        Concat c; std::string err;
+        if (!concatenate(ngenes, genes, s, c, err)) return PML_EINVAL;
+        std::string txt;
+        for (size_t i = 0; i < c.names.size(); ++i) { txt += '>'; txt += c.names[i]; txt += '\n'; txt += c.rows[i]; txt += '\n'; }
+        *fasta_out = dup_cstr(txt);
+    } catch (const std::exception &) { return PML_ENOMEM; }
+    return *fasta_out ? PML_OK : PML_ENOMEM;
+}
+
+extern "C" int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *genes, const pml_model *model,
+                             const pml_jackknife_opts *opts, pml_result *main_out, char **support_out) {
+    if (!ctx || !genes || ngenes <= 0 || !main_out) return PML_EINVAL;
+    std::memset(main_out, 0, sizeof *main_out);
+    if (support_out) *support_out = nullptr;
+    const int reps = opts ? opts->reps : 100;
+    int subset = (opts && opts->subset_size > 0) ? opts->subset_size : ngenes / 2;
+    subset = std::max(1, std::min(subset, ngenes));
+    const double eps = (opts && opts->epsilon > 0) ? opts->epsilon : 1e-3;
+    const int spr_full = opts ? opts->spr_radius_full : 5;
+    if (reps < 0) return PML_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->c.mu);
+    try {
+        std::string err;
+        std::vector<int> all(ngenes); for (int i = 0; i < ngenes; ++i) all[i] = i;
+        Concat full;
+        if (!concatenate(ngenes, genes, all, full, err)) return ctx->c.fail(PML_EINVAL, err);
+        // replicates: seeded draw without replacement (reference: RandomSetUtils.getRandomSet, unseeded)
+        std::mt19937_64 rng(opts ? opts->seed : 0);
+        std::vector<Concat> rep((size_t)reps);
+        for (int r = 0; r < reps; ++r) {
+            std::vector<int> pool(all);
+            for (int i = 0; i < subset; ++i) { const size_t j = i + (size_t)(rng() % (uint64_t)(ngenes - i)); std::swap(pool[i], pool[j]); }
+            std::vector<int> sel(pool.begin(), pool.begin() + subset);
+            std::sort(sel.begin(), sel.end());
+            if (!concatenate(ngenes, genes, sel, rep[r], err)) return ctx->c.fail(PML_EINVAL, err);
+        }
+        auto view = [](const Concat &c, std::vector<const char *> &np, std::vector<const char *> &rp) {
+            np.clear(); rp.clear();
+            for (auto &s : c.names) np.push_back(s.c_str());
+            for (auto &s : c.rows) rp.push_back(s.c_str());
+            return pml_alignment_view{(int)c.names.size(), (int)c.rows[0].size(), np.data(), rp.data()};
+        };
+        const int ncat = model ? model->ncat : 4, pm = model ? model->pi_mode : 0;
+        const double alpha = model ? model->alpha : 1.0;
+        // full tree
+        Tree main_tree; std::vector<std::string> main_names; double main_lnl = 0, main_alpha = alpha; int main_npat = 0;
+        {
+            std::vector<const char *> np, rp; pml_alignment_view v = view(full, np, rp);
+            Batch b; int rc = b.create(&ctx->c, 1, &v, nullptr, pm, ncat, alpha, false);
+            if (!rc) rc = b.search(true, spr_full, true, eps, &main_lnl);
+            if (rc) { b.destroy(); return rc; }
+            main_tree = b.genes[0].tree; main_names = b.genes[0].aln.names; main_alpha = b.genes[0].alpha; main_npat = b.genes[0].aln.npat;
+            b.destroy();
+        }
+        // support trees: one batch
+        std::vector<Tree> sup((size_t)reps);
+        std::string sup_txt;
+        if (reps > 0) {
+            std::vector<std::vector<const char *>> nps(reps), rps(reps);
+            std::vector<pml_alignment_view> vs(reps);
+            for (int r = 0; r < reps; ++r) vs[r] = view(rep[r], nps[r], rps[r]);
+            Batch b; int rc = b.create(&ctx->c, reps, vs.data(), nullptr, pm, ncat, alpha, false);
+            std::vector<double> l(reps);
+            if (!rc) rc = b.search(true, 0, true, eps, l.data());
+            if (rc) { b.destroy(); return rc; }
+            for (int r = 0; r < reps; ++r) {
+                const Gene &G = b.genes[r];
+                const std::string nw = G.tree.newick(G.aln.names, 6);
+                sup_txt += nw; sup_txt += '\n';
+                // a replicate may lack taxa that occur only in unselected genes: such trees cannot
+                // contain the main tree's bipartitions and are counted as not supporting
+                if (G.aln.names == main_names) sup[r] = G.tree;
+                else { std::string e2; Tree t; if (Tree::parse(nw.c_str(), main_names, t, e2)) sup[r] = t; else sup[r] = Tree(); }
+            }
+            b.destroy();
+        }
+        std::vector<Tree> usable;
+        for (auto &t : sup) if (t.ntax == main_tree.ntax) usable.push_back(t);
+        const std::string out = main_tree.newick_labeled(main_names, 6, support_counts(main_tree, usable));
+        main_out->lnl = main_lnl; main_out->alpha = main_alpha; main_out->tree_length = main_tree.length();
+        main_out->npatterns = main_npat; main_out->nsites = (int)full.rows[0].size();
+        main_out->newick = dup_cstr(out);
+        if (support_out) *support_out = dup_cstr(sup_txt);
+        if (!main_out->newick) return ctx->c.fail(PML_ENOMEM, "host allocation failed");
+    } catch (const std::bad_alloc &) { return ctx->c.fail(PML_ENOMEM, "host allocation failed"); }
+    catch (const std::exception &e) { return ctx->c.fail(PML_EINVAL, e.what()); }
+    return PML_OK;
+}

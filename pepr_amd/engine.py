@@ -104,6 +104,27 @@ class Context:
         o = _opts(optimize_alpha, nni, spr_radius, epsilon)
         return self._oneshot(self.L.pml_search_batch, genes, start_newicks, _model(ncat, alpha, pi_mode), (C.byref(o),))
 
+    def jackknife(self, genes, reps=100, subset_size=0, seed=0, spr_radius_full=5, epsilon=1e-3, alpha=1.0,
+                  ncat=4, pi_mode=PI_RAXML_3DP):
+        """Full tree + `reps` gene-subset support trees + support counts (PhylogenomicPipeline2.java:994-1126).
+        genes: list of (names, rows), possibly over different taxon subsets."""
+        keep = []
+        n = len(genes)
+        alns = (_lib.Alignment * n)(*[_aln_struct(g[0], g[1], keep) for g in genes])
+        o = _lib.JackknifeOpts(reps, subset_size, seed, spr_radius_full, epsilon)
+        m = _model(ncat, alpha, pi_mode)
+        res = _lib.Result()
+        sup = C.c_void_p()
+        rc = self.L.pml_jackknife(self.ptr, n, alns, C.byref(m), C.byref(o), C.byref(res), C.byref(sup))
+        self._check(rc)
+        out = {"lnl": res.lnl, "alpha": res.alpha, "tree_length": res.tree_length, "npatterns": res.npatterns,
+               "nsites": res.nsites, "newick": C.string_at(res.newick).decode(),
+               "support_trees": C.string_at(sup).decode().splitlines() if sup else []}
+        self.L.pml_result_free(C.byref(res))
+        if sup:
+            self.L.pml_free(sup)
+        return out
+
     def kernel_stats(self, reset=False):
         out = {}
         for name, k in KERNELS.items():
@@ -207,3 +228,23 @@ def support_tree(main_newick, support_newicks, digits=6):
     s = C.string_at(p).decode()
     L.pml_free(p)
     return s
+
+
+def concatenate(genes, sel=None):
+    """Sorted-taxon-union concatenation with '?' padding (MSAConcatenator.java:78-189) -> (names, rows)."""
+    L = _lib.load()
+    keep = []
+    n = len(genes)
+    alns = (_lib.Alignment * n)(*[_aln_struct(g[0], g[1], keep) for g in genes])
+    p = C.c_void_p()
+    if sel is None:
+        rc = L.pml_concatenate(n, alns, 0, None, C.byref(p))
+    else:
+        arr = (C.c_int * len(sel))(*sel)
+        rc = L.pml_concatenate(n, alns, len(sel), arr, C.byref(p))
+    if rc:
+        raise PmlError(rc)
+    txt = C.string_at(p).decode()
+    L.pml_free(p)
+    lines = txt.splitlines()
+    return [l[1:] for l in lines[0::2]], lines[1::2]

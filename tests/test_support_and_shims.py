@@ -56,3 +56,16 @@ def test_shim_fails_loudly_without_gpu(tmp_path):
     (tmp_path / "a.faa").write_text(">a\nARND\n>b\nARNE\n>c\nAQND\n>d\nGRND\n")
     r = subprocess.run([FT, "-gamma", "-nosupport", "a.faa"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode != 0 and "HIP device" in r.stderr and r.stdout == ""
+
+
+def test_concatenate_matches_reference_rules():
+    """MSAConcatenator.concatenate (MSAConcatenator.java:78-189): sorted taxon union, '?' padding."""
+    g = [(["b", "a", "c"], ["AR", "NN", "DD"]), (["c", "d", "a"], ["KKK", "LLL", "MMM"]), (["a", "b", "c", "d"], ["W", "Y", "V", "F"])]
+    names, rows = engine.concatenate(g)
+    assert names == ["a", "b", "c", "d"] and rows == ["NNMMMW", "AR???Y", "DDKKKV", "??LLLF"]
+    names, rows = engine.concatenate(g, [2, 0])
+    assert names == ["a", "b", "c", "d"] and rows == ["WNN", "YAR", "VDD", "F??"]
+    names, rows = engine.concatenate(g, [1])
+    assert names == ["a", "c", "d"] and rows == ["MMM", "KKK", "LLL"]
+    with pytest.raises(engine.PmlError):
+        engine.concatenate(g, [7])
