@@ -497,6 +497,7 @@ struct po_engine {
     const po_tree *bound;   /* tree the cache refers to */
     double tipvec[PO_NCODES][PO_NS];
     double *sumtab;    /* npat*K*20 */
+    double ntol;       /* Newton stop: |dt| < ntol (1e-8 fine, 1e-6 coarse phases) */
     long n_newview, n_evaluate, n_deriv;
 };
 
@@ -508,6 +509,7 @@ po_engine *po_engine_create(const po_aln *a, const po_model *m, int ncat, double
     e->valid = (unsigned char *)calloc(nd, 1);
     for (int c = 0; c < PO_NCODES; c++) { unsigned mk = po_code_mask(c); for (int s = 0; s < 20; s++) e->tipvec[c][s] = (mk >> s) & 1 ? 1.0 : 0.0; }
     e->sumtab = (double *)malloc(sizeof(double) * (size_t)(e->npat > 0 ? e->npat : 1) * ncat * 20);
+    e->ntol = 1e-8;
     po_engine_set_alpha(e, alpha);
     return e;
 }
@@ -682,7 +684,7 @@ void po_engine_branch_derivs(po_engine *e, const po_tree *t, int u, int v, doubl
  * Spec (mirrored by the HIP engine, see DESIGN.md "branch Newton"):
  *   t0 = clamp(t); up to 32 iterations: (L,d1,d2) at t; if d2<0 step=-d1/d2 else step = d1>0 ? t : -t/2;
  *   tn = clamp(t+step, TMIN, TMAX); backtrack (halve step, <=8x) while L(tn) < L(t) - 1e-9;
- *   stop when |tn-t| < 1e-8 */
+ *   stop when |tn-t| < e->ntol */
 static double eng_newton_branch(po_engine *e, double t0, double *lnl_out) {
     double t = t0 < PO_TMIN ? PO_TMIN : (t0 > PO_TMAX ? PO_TMAX : t0);
     double L, d1, d2;
@@ -699,7 +701,7 @@ static double eng_newton_branch(po_engine *e, double t0, double *lnl_out) {
         if (Ln < L - 1e-9) break;            /* could not improve: keep t */
         double dt = fabs(tn - t);
         t = tn; L = Ln; d1 = n1; d2 = n2;
-        if (dt < 1e-8) break;
+        if (dt < e->ntol) break;
     }
     if (lnl_out) *lnl_out = L;
     return t;
@@ -755,12 +757,18 @@ double po_engine_optimize(po_engine *e, po_tree *t, int opt_alpha, double eps) {
     for (int i = 0; i < t->nnodes; i++) for (int k = 0; k < 3; k++) if (t->nbr[i][k] >= 0 && t->len[i][k] < PO_TMIN) t->len[i][k] = PO_TMIN;
     eng_invalidate_all(e);
     double lnl = po_engine_lnl(e, t, NULL);
+    /* coarse level (eps >= 0.05: the search's intermediate optimisations): <= 8 passes per round until
+     * max |dt| < 1e-3, Newton to 1e-6; fine level: <= 16 passes until 1e-6, Newton to 1e-8 */
+    const int coarse = eps >= 0.05, maxpass = coarse ? 8 : 16;
+    const double thr = coarse ? 1e-3 : 1e-6, save = e->ntol;
+    e->ntol = coarse ? 1e-6 : 1e-8;
     for (int round = 0; round < 100; round++) {
-        for (int pass = 0; pass < 16; pass++) { if (eng_smooth(e, t) < 1e-6) break; }
+        for (int pass = 0; pass < maxpass; pass++) { if (eng_smooth(e, t) < thr) break; }
         double nl = opt_alpha ? eng_opt_alpha(e, t) : po_engine_lnl(e, t, NULL);
         double gain = nl - lnl; lnl = nl;
         if (gain < eps) break;
     }
+    e->ntol = save;
     return lnl;
 }
 
@@ -1062,6 +1070,7 @@ double po_engine_search(po_engine *e, po_tree **t_inout, int spr_radius, double 
     if (!*t_inout) *t_inout = po_nj_tree(e->a);
     po_tree *t = *t_inout;
     eng_bind(e, t);
+    e->ntol = 1e-6;                      /* candidate ranking and local moves: coarse Newton */
     double lnl = po_engine_optimize(e, t, 1, 0.1);
     for (int outer = 0; outer < 20; outer++) {
         int moves = 0;
@@ -1070,5 +1079,6 @@ double po_engine_search(po_engine *e, po_tree **t_inout, int spr_radius, double 
         lnl = po_engine_optimize(e, t, 1, 0.1);
         if (!moves) break;
     }
+    e->ntol = 1e-8;
     return po_engine_optimize(e, t, 1, eps);
 }

@@ -378,7 +378,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
                 NewtonReq &nr = hnewt[in];
                 nr.sumtab = G.d_sumtab; nr.weight = G.d_weight; nr.scl = G.d_sumscl;
                 std::memcpy(nr.rates, G.rates, sizeof nr.rates);
-                nr.t0 = t.t0; nr.out = d_scalars + 8 * g; nr.mpad = mp; nr.max_iter = t.max_iter;
+                nr.t0 = t.t0; nr.tol = newton_tol; nr.out = d_scalars + 8 * g; nr.mpad = mp; nr.max_iter = t.max_iter;
                 nr.sync = d_nsync + (size_t)in * NEWTON_SYNC_DOUBLES; newton_maxm = std::max(newton_maxm, mp);
                 algo_bytes += (double)G.aln.npat * ((lt ? 1 : 640) + (rt ? 1 : 640) + 640);
                 in++;
@@ -547,15 +547,22 @@ int Batch::optimize(bool opt_alpha_flag, double eps, double *lnl, const std::vec
     const std::vector<char> initial(active);
     std::vector<double> cur(n), nl(n), md;
     if (int rc = evaluate(active, cur.data())) return rc;
+    // coarse level (eps >= 0.05): <= 8 passes per round until max |dt| < 1e-3, Newton to 1e-6;
+    // fine level: <= 16 passes until 1e-6, Newton to 1e-8 (oracle: po_engine_optimize)
+    const bool coarse = eps >= 0.05;
+    const int maxpass = coarse ? 8 : 16;
+    const double thr = coarse ? 1e-3 : 1e-6, save_tol = newton_tol;
+    newton_tol = coarse ? 1e-6 : 1e-8;
+    struct Restore { double &r; double v; ~Restore() { r = v; } } restore{newton_tol, save_tol};
     for (int round = 0; round < 100; ++round) {
         bool any = false; for (char a : active) any |= a;
         if (!any) break;
         std::vector<char> sm(active);
-        for (int pass = 0; pass < 16; ++pass) {
+        for (int pass = 0; pass < maxpass; ++pass) {
             bool anys = false; for (char a : sm) anys |= a;
             if (!anys) break;
             if (int rc = smooth_pass(sm, md)) return rc;
-            for (int g = 0; g < n; ++g) if (sm[g] && md[g] < 1e-6) sm[g] = 0;
+            for (int g = 0; g < n; ++g) if (sm[g] && md[g] < thr) sm[g] = 0;
         }
         if (opt_alpha_flag) { if (int rc = opt_alpha(active, nl.data())) return rc; }
         else { if (int rc = evaluate(active, nl.data())) return rc; }

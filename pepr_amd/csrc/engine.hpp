@@ -67,6 +67,7 @@ struct PendingOp { int gene, out_kind, out_id, level; Side child[2]; double t[2]
 struct Batch {
     Ctx *ctx = nullptr;
     int pi_mode = 0, ncat = 4;
+    double newton_tol = 1e-8;      // Newton stop |dt| < tol: 1e-8 fine, 1e-6 in coarse phases
     std::vector<Gene> genes;
     char *arena = nullptr; size_t arena_bytes = 0;
     // staging (pinned host mirrors + device buffers), grown on demand

@@ -64,6 +64,7 @@ struct NewtonReq {          // Newton-Raphson on one branch from its sumtable
     const int *scl;         // [mpad] combined scaling counts
     double rates[NCAT];
     double t0;
+    double tol;             // stop when |dt| < tol
     double *out;            // out[0]=t, out[1]=lnL, out[2]=d1, out[3]=d2 (at returned t)
     double *sync;           // NEWTON_SYNC_DOUBLES zeroed doubles: arrival counter + per-workgroup partial sums
     int mpad;

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void k_newton(const ModelDev *__restrict__ md,
         if (failed || Ln < L - 1e-9) break;
         const double dt = fabs(tn - t);
         t = tn; L = Ln; d1 = n1; d2 = n2;
-        if (dt < 1e-8) break;
+        if (dt < r.tol) break;
     }
     if (tid == 0 && wg == 0) {
         if (failed) { t = r.t0; L = __builtin_nan(""); }

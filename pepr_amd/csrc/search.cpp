@@ -306,6 +306,8 @@ int Batch::spr_round(const std::vector<char> &active, int radius, std::vector<do
 int Batch::search(bool nni, int spr_radius, bool opt_alpha_flag, double eps, double *lnl_out) {
     const int n = (int)genes.size();
     std::vector<double> lnl(n, 0.0);
+    newton_tol = 1e-6;                    // candidate ranking and local moves: coarse Newton
+    struct Restore { double &r; ~Restore() { r = 1e-8; } } restore{newton_tol};
     if (int rc = optimize(opt_alpha_flag, 0.1, lnl.data())) return rc;
     std::vector<char> active(n, (nni || spr_radius > 0) ? 1 : 0);
     for (int outer = 0; outer < 20; ++outer) {
@@ -332,6 +334,7 @@ int Batch::search(bool nni, int spr_radius, bool opt_alpha_flag, double eps, dou
         if (int rc = optimize(opt_alpha_flag, 0.1, lnl.data(), &active)) return rc;
         for (int g = 0; g < n; ++g) if (active[g] && moves[g] == 0) active[g] = 0;
     }
+    newton_tol = 1e-8;
     if (int rc = optimize(opt_alpha_flag, eps, lnl.data())) return rc;
     for (int g = 0; g < n; ++g) lnl_out[g] = lnl[g];
     return 0;
