@@ -9,8 +9,10 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <thread>
 #include <cstring>
 
 namespace pml {
@@ -103,15 +105,28 @@ int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *con
     std::string err;
     size_t total = 0;
     std::vector<size_t> off(n);
+    {   // encode / parse / NJ are independent per gene: host threads (plain std::thread, no GPU work)
+        const int nthreads = std::max(1, std::min({n, 16, (int)std::thread::hardware_concurrency()}));
+        std::vector<std::string> errs(n);
+        std::atomic<int> next{0};
+        auto work = [&]() {
+            for (int g = next++; g < n; g = next++) {
+                Gene &G = genes[g];
+                try {
+                    if (!G.aln.encode(alns[g].ntax, alns[g].nsites, alns[g].names, alns[g].rows, errs[g])) continue;
+                    if (newicks && newicks[g]) { if (!Tree::parse(newicks[g], G.aln.names, G.tree, errs[g])) continue; }
+                    else G.tree = nj_tree(G.aln);
+                } catch (const std::exception &e) { errs[g] = e.what(); }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+        for (int g = 0; g < n; ++g) if (!errs[g].empty()) return ctx->fail(-2, "gene " + std::to_string(g) + ": " + errs[g]);
+    }
     for (int g = 0; g < n; ++g) {
         Gene &G = genes[g];
-        if (!G.aln.encode(alns[g].ntax, alns[g].nsites, alns[g].names, alns[g].rows, err))
-            return ctx->fail(-2, "gene " + std::to_string(g) + ": " + err);
-        if (newicks && newicks[g]) {
-            if (!Tree::parse(newicks[g], G.aln.names, G.tree, err)) return ctx->fail(-2, "gene " + std::to_string(g) + ": " + err);
-        } else {
-            G.tree = nj_tree(G.aln);
-        }
         const int nt = G.aln.ntax, mp = G.aln.mpad, ndir = 3 * (nt - 2);
         G.slot_cap = score_only ? (nt - 2) : ndir;
         G.slot_of.assign(ndir, -1); G.valid.assign(ndir, 0); G.pend_level.assign(ndir, -1);
@@ -144,8 +159,10 @@ int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *con
         HIPCHK(hipMemcpyAsync(G.d_weight, G.aln.weight.data(), (size_t)mp * 8, hipMemcpyHostToDevice, ctx->stream));
         set_alpha(g, alpha);
     }
-    HIPCHK(hipMalloc((void **)&d_scalars, sizeof(double) * 8 * n));
-    HIPCHK(hipHostMalloc((void **)&h_scalars, sizeof(double) * 8 * n));
+    // results (8 doubles per gene) are written by the kernels straight into mapped pinned host
+    // memory: no device-to-host copy node per step
+    HIPCHK(hipHostMalloc((void **)&h_scalars, sizeof(double) * 8 * n, hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void **)&d_scalars, h_scalars, 0));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -157,7 +174,6 @@ void Batch::destroy() {
     if (h_stage) hipHostFree(h_stage);
     if (d_stage) hipFree(d_stage);
     if (d_frags) hipFree(d_frags);
-    if (d_scalars) hipFree(d_scalars);
     if (d_nsync) hipFree(d_nsync);
     d_nsync = nullptr;
     if (h_scalars) hipHostFree(h_scalars);
@@ -375,6 +391,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             } else {
                 d.pl = eig; d.pr = eig + PFRAG;
                 d.out = G.d_sumtab; d.out_scl = G.d_sumscl;
+                d.aux = d_nsync + (size_t)in * NEWTON_SYNC_DOUBLES;
                 NewtonReq &nr = hnewt[in];
                 nr.sumtab = G.d_sumtab; nr.weight = G.d_weight; nr.scl = G.d_sumscl;
                 std::memcpy(nr.rates, G.rates, sizeof nr.rates);
@@ -407,13 +424,10 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     if (nnewton) {
         double nb = 0;
         for (auto &t : tails) if (t.mode != MODE_EVALUATE) nb += (double)genes[t.gene].aln.npat * 640;
-        HIPCHK(hipMemsetAsync(d_nsync, 0, nnewton * NEWTON_SYNC_DOUBLES * sizeof(double), ctx->stream));
         ctx->tic(K_NEWTON, nb);
         launch_newton(md, (const NewtonReq *)(ds + o_newt), (int)nnewton, newton_maxm, ctx->stream);
         ctx->toc();
     }
-    if (!tails.empty())
-        HIPCHK(hipMemcpyAsync(h_scalars, d_scalars, sizeof(double) * 8 * genes.size(), hipMemcpyDeviceToHost, ctx->stream));
     const double t_launched = now_ms();
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());

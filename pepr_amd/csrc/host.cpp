@@ -419,11 +419,18 @@ int rf_distance(const Tree &a, const Tree &b) {
 Tree nj_tree(const EncodedAlignment &a) {
     const int n = a.ntax, N = 2 * n - 2, mp = a.mpad;
     std::vector<double> D((size_t)N * N, 0.0);
+    std::vector<int32_t> w(a.npat);
+    for (int p = 0; p < a.npat; ++p) w[p] = (int32_t)a.weight[p];
     for (int i = 0; i < n; ++i)
         for (int j = i + 1; j < n; ++j) {
-            double cmp = 0, diff = 0;
+            // branch-free integer counts (auto-vectorised); sums of integer weights are exact
+            int64_t icmp = 0, idiff = 0;
             const uint8_t *ci = &a.codes[(size_t)i * mp], *cj = &a.codes[(size_t)j * mp];
-            for (int p = 0; p < a.npat; ++p) if (ci[p] < 20 && cj[p] < 20) { cmp += a.weight[p]; if (ci[p] != cj[p]) diff += a.weight[p]; }
+            for (int p = 0; p < a.npat; ++p) {
+                const int32_t ok = (ci[p] < 20) & (cj[p] < 20);
+                icmp += ok * w[p]; idiff += (ok & (ci[p] != cj[p])) * w[p];
+            }
+            const double cmp = (double)icmp, diff = (double)idiff;
             double d = 3.0;
             if (cmp > 0) { const double pd = diff / cmp; d = -std::log(std::max(1.0 - pd - 0.2 * pd * pd, 0.05)); }
             D[(size_t)i * N + j] = D[(size_t)j * N + i] = d;

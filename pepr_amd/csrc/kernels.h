@@ -42,8 +42,9 @@ struct NvOp {
     int flags;              // bit0: left is tip, bit1: right is tip
     int mode;               // MODE_NEWVIEW / MODE_SUMTABLE / MODE_EVALUATE
     int pad;
+    double *aux;            // sumtable ops: the Newton sync block to zero (NEWTON_SYNC_DOUBLES), else null
 };
-static_assert(sizeof(NvOp) == 80, "NvOp layout");
+static_assert(sizeof(NvOp) == 88, "NvOp layout");
 
 // ops [op_begin, op_end) of one gene, in dependency order; executed by every pattern block
 struct GeneRun {

@@ -290,6 +290,7 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : 3) void k_oplist(
             __syncthreads();
         }
         if (active) chunk_op<PREFETCH>(op, buf, sT, p, lane);
+        if (op.aux != nullptr && blk == 0 && tid < NEWTON_SYNC_DOUBLES) op.aux[tid] = 0.0;   // arm k_newton's arrival counter
         if (DBUF) __syncthreads();           // next fragments landed (vmcnt(0) + barrier), stores done
     }
 }
