@@ -246,3 +246,25 @@ def test_spr_search_vs_oracle(gpu_ctx, oracle_lib):
         assert util.rf_collapsed(r["newick"], tree.newick(12)) == 0
         assert abs(r["lnl"] - lnl) < 1e-3
         assert lnl >= lnl_nni - 1e-6            # SPR never ends below NNI-only
+
+
+def test_tiny_and_degenerate_inputs(gpu_ctx, oracle_lib):
+    """3 and 4 taxa (no / one internal edge), a single column, an all-gap alignment, identical
+    sequences: search, optimise and score must stay finite and agree with the oracle."""
+    po = oracle_lib
+    cases = [(["a", "b", "c"], ["ARNDC", "ARNDD", "AQNDC"]),
+             (["a", "b", "c", "d"], ["ARNDCQ", "ARNDDQ", "AQNDCE", "AQNECE"]),
+             (["a", "b", "c", "d", "e"], ["K", "K", "R", "R", "-"]),
+             (["a", "b", "c", "d"], ["----", "????", "XXXX", "----"]),
+             (["a", "b", "c", "d", "e", "f"], ["ARNDCQEGHI"] * 6)]
+    for names, rows in cases:
+        a = po.Alignment(names, rows)
+        e = po.Engine(a, po.Model(0), 4, 1.0)
+        lnl, tree = e.search(None, 5, 1e-3)
+        r = gpu_ctx.search([(names, rows)], None, nni=True, spr_radius=5, epsilon=1e-3)[0]
+        assert np.isfinite(r["lnl"]) and abs(r["lnl"] - lnl) < 1e-3, (names, r["lnl"], lnl)
+        s = gpu_ctx.score([(names, rows)], [r["newick"]], alpha=r["alpha"], site_lnl=True)[0]
+        assert abs(s["lnl"] - r["lnl"]) < 1e-6 and len(s["site_lnl"]) == len(rows[0])
+    # all-gap alignment: every site likelihood is 1
+    s = gpu_ctx.score([cases[3]], ["(a:0.1,b:0.2,(c:0.3,d:0.4):0.5);"])[0]
+    assert abs(s["lnl"]) < 1e-12
