@@ -54,26 +54,33 @@ __device__ __forceinline__ void frag_decode(int idx, int &c, int &row, int &col)
 // ------------------------------------------------------------------------------------------
 // k_pmat: P(t r_c) = U diag(exp(lambda t r_c)) U^-1, written directly in MFMA A-fragment order
 // ------------------------------------------------------------------------------------------
+// One block per request.  Thread (row = c*20+s, group g) keeps W[k] = U[s][k] exp(lambda_k r_c t) in
+// registers and produces the outputs j = g, g+3, g+6, ...: one LDS read per FMA instead of three.
 __global__ __launch_bounds__(256) void k_pmat(const ModelDev *__restrict__ md,
                                               const PmatReq *__restrict__ reqs,
-                                              double *__restrict__ frags) {
+                                              double *__restrict__ frags, int n) {
     __shared__ double e[NCAT * NS];
-    __shared__ double sU[NS * NS], sUi[NS * NS];
-    const PmatReq req = reqs[blockIdx.x];
+    __shared__ double sUi[NS * NS];
     const int tid = threadIdx.x;
-    for (int i = tid; i < NS * NS; i += 256) { sU[i] = md->U[i]; sUi[i] = md->Uinv[i]; }
+    const PmatReq req = reqs[blockIdx.x];
+    for (int i = tid; i < NS * NS; i += 256) sUi[i] = md->Uinv[i];
     if (tid < NCAT * NS) e[tid] = exp(md->eval[tid % NS] * (req.t * req.rates[tid / NS]));
     __syncthreads();
+    if (tid >= 3 * NCAT * NS) return;
+    const int row = tid % (NCAT * NS), g = tid / (NCAT * NS);
+    const int c = row / NS, s2 = row % NS;
+    double W[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) W[k] = md->U[s2 * NS + k] * e[c * NS + k];
+    const double scale = req.fold_pi ? md->pi[s2] : 1.0;
     double *out = frags + (size_t)blockIdx.x * PFRAG;
-    for (int idx = tid; idx < PFRAG; idx += 256) {
-        int c, s, j;
-        frag_decode(idx, c, s, j);
+    for (int j = g; j < NS; j += 3) {
         double v = 0.0;
 #pragma unroll
-        for (int k = 0; k < NS; ++k) v += sU[s * NS + k] * e[c * NS + k] * sUi[k * NS + j];
+        for (int k = 0; k < NS; ++k) v += W[k] * sUi[k * NS + j];
         if (v < 0.0) v = 0.0;
-        if (req.fold_pi) v *= md->pi[s];
-        out[idx] = v;
+        // fragment element (c, st = s/4, kk = j/4)[4*(j%4) + s%4]
+        out[((c * 25 + (s2 >> 2) * 5 + (j >> 2)) << 4) + ((j & 3) << 2) + (s2 & 3)] = v * scale;
     }
 }
 
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(256) void k_newton(const ModelDev *__restrict__ md,
 // ------------------------------------------------------------------------------------------
 void launch_pmat(const ModelDev *model, const PmatReq *reqs, double *frags, int n, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_pmat, dim3(n), dim3(256), 0, s, model, reqs, frags);
+    hipLaunchKernelGGL(k_pmat, dim3(n), dim3(256), 0, s, model, reqs, frags, n);
 }
 void launch_eigfrags(const ModelDev *model, double *frags2, hipStream_t s) {
     hipLaunchKernelGGL(k_eigfrags, dim3(1), dim3(256), 0, s, model, frags2);
