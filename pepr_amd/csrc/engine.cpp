@@ -96,7 +96,7 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *const *newicks, int pm, int nc,
                   double alpha, bool score_only) {
-    ctx = c; pi_mode = pm; ncat = nc;
+    ctx = c; pi_mode = pm; ncat = nc; score_only_batch = score_only;
     if (n <= 0) return ctx->fail(-1, "empty batch");
     if (nc != 1 && nc != 4) return ctx->fail(-1, "ncat must be 1 or 4");
     if (int rc = ctx->ensure_model(pm)) return rc;
@@ -176,6 +176,9 @@ void Batch::destroy() {
     if (d_frags) hipFree(d_frags);
     if (d_nsync) hipFree(d_nsync);
     d_nsync = nullptr;
+    if (plan.h) hipHostFree(plan.h);
+    if (plan.d) hipFree(plan.d);
+    plan = Plan();
     if (h_scalars) hipHostFree(h_scalars);
     arena = nullptr; h_stage = d_stage = nullptr; d_frags = nullptr; d_scalars = h_scalars = nullptr;
 }
@@ -195,7 +198,7 @@ int Batch::ensure_frags(size_t sets) {
     if (sets <= frag_cap) return 0;
     const size_t cap = std::max(sets * 5 / 4, (size_t)256);
     if (d_frags) hipFree(d_frags);
-    d_frags = nullptr; frag_cap = 0;
+    d_frags = nullptr; frag_cap = 0; plan.valid = false;      // cached descriptors point into d_frags
     HIPCHK(hipMalloc((void **)&d_frags, cap * PFRAG * sizeof(double)));
     frag_cap = cap;
     return 0;
@@ -341,6 +344,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         tail_of[tails[i].gene] = (int)i;
     }
     size_t nout = 0, nruns = 0, ie = 0, in = 0, ireq = 0, iop = 0;
+    last_src.clear();
     int max_mpad = 0, newton_maxm = 0;
     double algo_bytes = 0;
     for (size_t g = 0; g < ngenes; ++g) {
@@ -369,6 +373,13 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             for (int c = 0; c < 2; ++c) {
                 PmatReq &r = hreq[ireq++];
                 r.t = o.t[c]; std::memcpy(r.rates, G.rates, sizeof r.rates); r.fold_pi = 0; r.pad = 0;
+                // remember where this branch length lives (plan replay): message o.out_id = (v, k), child c
+                if (o.out_kind == SIDE_MSG) {
+                    const int v = G.aln.ntax + o.out_id / 3, k = o.out_id % 3;
+                    int q = 0, seen = 0;
+                    for (; q < 3; ++q) if (q != k) { if (seen == c) break; ++seen; }
+                    last_src.push_back({(int)g, v, q, 0});
+                } else last_src.push_back({(int)g, -1, 0, 0});
             }
             algo_bytes += (double)G.aln.npat * ((lt ? 1 : 640) + (rt ? 1 : 640) + 640);
         }
@@ -383,6 +394,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             if (t.mode == MODE_EVALUATE) {
                 PmatReq &r = hreq[ireq];
                 r.t = t.t0; std::memcpy(r.rates, G.rates, sizeof r.rates); r.fold_pi = 1; r.pad = 0;
+                last_src.push_back({(int)g, 0, 0, 1});          // root evaluation: branch above taxon 0
                 d.pl = d.pr = d_frags + ireq * PFRAG; ireq++;
                 d.out = G.d_patlnl; d.out_scl = nullptr;
                 ReduceReq &rr = hred[ie++];
@@ -436,6 +448,60 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += t_done - t_launched;
     ctx->resolve_events();
     for (auto &o : ops) if (o.out_kind == SIDE_MSG) { Gene &G = genes[o.gene]; G.valid[o.out_id] = 1; G.pend_level[o.out_id] = -1; }
+    if (record_plan) {                       // keep the descriptors of this full-traversal score
+        record_plan = false;
+        Plan &P = plan;
+        if (P.bytes < bytes) {
+            if (P.h) hipHostFree(P.h);
+            if (P.d) hipFree(P.d);
+            P.h = P.d = nullptr; P.bytes = 0;
+            HIPCHK(hipHostMalloc(&P.h, bytes)); HIPCHK(hipMalloc(&P.d, bytes)); P.bytes = bytes;
+        }
+        std::memcpy(P.h, hs, bytes);
+        HIPCHK(hipMemcpy(P.d, ds, bytes, hipMemcpyDeviceToDevice));
+        P.o_req = o_req; P.o_ops = o_ops; P.o_runs = o_runs; P.o_red = o_red;
+        P.nreq = ireq; P.nruns = nruns; P.neval = neval; P.max_mpad = max_mpad; P.algo_bytes = algo_bytes;
+        P.src = last_src; P.outs.clear();
+        for (auto &o : ops) if (o.out_kind == SIDE_MSG) P.outs.push_back({o.gene, o.out_id});
+        P.epoch = topo_epoch; P.valid = true;
+    }
+    return 0;
+}
+
+// full-traversal score of all genes from cached descriptors: refresh branch lengths / rates, then
+// k_pmat + k_oplist + k_reduce exactly as run() would launch them
+int Batch::replay_plan(double *lnl) {
+    const double t_begin = now_ms();
+    Plan &P = plan;
+    HIPCHK(hipSetDevice(ctx->device));
+    PmatReq *hreq = (PmatReq *)((char *)P.h + P.o_req);
+    for (size_t i = 0; i < P.nreq; ++i) {
+        const ReqSrc &s = P.src[i];
+        const Gene &G = genes[s.gene];
+        hreq[i].t = s.fold ? G.tree.len[0][0] : G.tree.len[s.v][s.q];
+        std::memcpy(hreq[i].rates, G.rates, sizeof hreq[i].rates);
+    }
+    char *ds = (char *)P.d;
+    HIPCHK(hipMemcpyAsync(ds + P.o_req, hreq, P.nreq * sizeof(PmatReq), hipMemcpyHostToDevice, ctx->stream));
+    const ModelDev *md = ctx->d_model[pi_mode];
+    ctx->tic(K_PMAT, (double)P.nreq * PFRAG * 8);
+    launch_pmat(md, (const PmatReq *)(ds + P.o_req), d_frags, (int)P.nreq, ctx->stream);
+    ctx->toc();
+    ctx->tic(K_NEWVIEW, P.algo_bytes);
+    launch_oplist((const NvOp *)(ds + P.o_ops), (const GeneRun *)(ds + P.o_runs), (int)P.nruns, P.max_mpad, ctx->stream);
+    ctx->toc();
+    ctx->tic(K_REDUCE, 0);
+    launch_reduce((const ReduceReq *)(ds + P.o_red), (int)P.neval, ctx->stream);
+    ctx->toc();
+    const double t_launched = now_ms();
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    const double t_done = now_ms();
+    ctx->stats[K_HOST_BUILD].launches++; ctx->stats[K_HOST_BUILD].ms += t_launched - t_begin;
+    ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += t_done - t_launched;
+    ctx->resolve_events();
+    for (auto &o : P.outs) genes[o.first].valid[o.second] = 1;
+    for (size_t g = 0; g < genes.size(); ++g) lnl[g] = h_scalars[8 * g];
     return 0;
 }
 
@@ -457,7 +523,15 @@ int Batch::evaluate(const std::vector<char> &active, double *lnl) {
 }
 int Batch::score(const std::vector<char> &active, double *lnl) {
     for (int g = 0; g < (int)genes.size(); ++g) if (active.empty() || active[g]) invalidate_all(g);
-    return evaluate(active, lnl);
+    bool all = true;
+    for (char a : active) all = all && a;
+    if (all && !score_only_batch) {
+        if (plan.valid && plan.epoch == topo_epoch) return replay_plan(lnl);
+        record_plan = true;
+    }
+    const int rc = evaluate(active, lnl);
+    record_plan = false;
+    return rc;
 }
 int Batch::site_lnl(int g, double *out) {
     Gene &G = genes[g];

@@ -76,6 +76,21 @@ struct Batch {
     double *d_frags = nullptr; size_t frag_cap = 0;      // in fragment sets
     double *d_scalars = nullptr; double *h_scalars = nullptr;   // 8 doubles per gene
     double *d_nsync = nullptr; size_t nsync_cap = 0;             // Newton inter-workgroup sync blocks
+    // cached descriptors of the full-traversal score of ALL genes (topology unchanged): replays skip
+    // the tree walk and the descriptor build; transition matrices, CLVs and lnL are recomputed
+    struct ReqSrc { int gene, v, q, fold; };
+    struct Plan {
+        bool valid = false; unsigned epoch = 0;
+        void *h = nullptr, *d = nullptr; size_t bytes = 0;
+        size_t o_req = 0, o_ops = 0, o_runs = 0, o_red = 0, nreq = 0, nruns = 0, neval = 0;
+        int max_mpad = 0; double algo_bytes = 0;
+        std::vector<ReqSrc> src; std::vector<std::pair<int, int>> outs;
+    } plan;
+    unsigned topo_epoch = 0;       // bumped whenever a search may change a topology
+    bool score_only_batch = false;
+    int replay_plan(double *lnl);
+    bool record_plan = false;
+    std::vector<ReqSrc> last_src;
 
     int create(Ctx *c, int n, const pml_alignment_view *alns, const char *const *newicks,
                int pi_mode, int ncat, double alpha, bool score_only);

@@ -57,6 +57,7 @@ int Batch::light_smooth(const std::vector<char> &active, double *lnl) {
 
 int Batch::nni_round(const std::vector<char> &active, std::vector<double> &lnl, std::vector<int> &applied) {
     const int n = (int)genes.size();
+    ++topo_epoch;
     applied.assign(n, 0);
     // per-gene edge lists in oracle order
     std::vector<std::vector<std::pair<int, int>>> edges(n);
@@ -178,6 +179,7 @@ void spr_apply(Tree &T, int p, int x, int y, int g, int h) {
 
 int Batch::spr_round(const std::vector<char> &active, int radius, std::vector<double> &lnl, std::vector<int> &moves) {
     const int n = (int)genes.size();
+    ++topo_epoch;
     moves.assign(n, 0);
     radius = std::min(radius, SPR_MAX_RADIUS);
     std::vector<SprState> st(n);

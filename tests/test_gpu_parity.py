@@ -268,3 +268,31 @@ def test_tiny_and_degenerate_inputs(gpu_ctx, oracle_lib):
     # all-gap alignment: every site likelihood is 1
     s = gpu_ctx.score([cases[3]], ["(a:0.1,b:0.2,(c:0.3,d:0.4):0.5);"])[0]
     assert abs(s["lnl"]) < 1e-12
+
+
+def test_cached_score_plan_tracks_changes(gpu_ctx):
+    """Batch.score() replays cached descriptors when the topology is unchanged: alpha, branch
+    length and topology changes in between must all be picked up."""
+    from pepr_amd import engine
+    genes = [synth.simulate_alignment(nt, ns, 600 + i) for i, (nt, ns) in enumerate([(9, 200), (15, 333), (6, 64)])]
+    G = [(g[0], g[1]) for g in genes]; NW = [g[2] for g in genes]
+    b = engine.Batch(gpu_ctx, G, NW, alpha=0.9)
+    l0 = b.score(); l1 = b.score()
+    assert np.array_equal(l0, l1)
+    ref = [r["lnl"] for r in gpu_ctx.score(G, NW, alpha=0.9)]
+    assert np.allclose(l0, ref, rtol=0, atol=1e-9)
+    b.set_alpha(0.4)
+    assert np.allclose(b.score(), [r["lnl"] for r in gpu_ctx.score(G, NW, alpha=0.4)], rtol=0, atol=1e-9)
+    lo, al = b.optimize(True, 1e-4)                      # branch lengths + per-gene alpha change
+    again = b.score()
+    assert np.allclose(again, lo, rtol=0, atol=1e-7)
+    for g in range(3):
+        one = gpu_ctx.score([G[g]], [b.newick(g, 17)], alpha=al[g])[0]["lnl"]
+        assert abs(one - again[g]) < 1e-8
+    ls, al2 = b.search(True, True, 5, 1e-3)              # topology may change
+    again = b.score()
+    assert np.allclose(again, ls, rtol=0, atol=1e-6)
+    for g in range(3):
+        one = gpu_ctx.score([G[g]], [b.newick(g, 17)], alpha=al2[g])[0]["lnl"]
+        assert abs(one - again[g]) < 1e-8
+    b.close()
