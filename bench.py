@@ -59,7 +59,11 @@ def main():
     import torch.distributed as dist
     from pepr_amd import distributed as pd, engine, synth
 
-    rank, local, world = pd.init_from_env()
+    # rehearsal knobs (not used by the driver): BENCH_BACKEND=gloo + BENCH_FORCE_DEVICE=0 let two
+    # ranks share the one GPU of a test box to exercise the N>1 path
+    rank, local, world = pd.init_from_env(os.environ.get("BENCH_BACKEND"))
+    if "BENCH_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["BENCH_FORCE_DEVICE"])
     if world != args.gpus and world > 1:
         args.gpus = world
     if not torch.cuda.is_available():
@@ -98,7 +102,7 @@ def main():
 
     tot_pat = npat
     if world > 1:
-        t = torch.tensor([dt, float(npat)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(npat)], dtype=torch.float64, device=pd._device())
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt, tot_pat = float(tmax[0]), float(tsum[1])
@@ -120,7 +124,7 @@ def main():
         rf = [engine.rf_distance(genes[i][2], sb.newick(i)) for i in range(len(genes))]
         sb.close()
         if world > 1:
-            t = torch.tensor([sdt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([sdt], dtype=torch.float64, device=pd._device())
             dist.all_reduce(t, op=dist.ReduceOp.MAX); sdt = float(t[0])
         search = {"gene_trees_per_sec": per_gpu * world / sdt, "seconds": sdt, "genes": per_gpu * world,
                   "algorithm": "NJ start + WAG+G4 model optimisation + NNI hill climbing (eps 1e-3)",
