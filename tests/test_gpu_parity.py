@@ -296,3 +296,24 @@ def test_cached_score_plan_tracks_changes(gpu_ctx):
         one = gpu_ctx.score([G[g]], [b.newick(g, 17)], alpha=al2[g])[0]["lnl"]
         assert abs(one - again[g]) < 1e-8
     b.close()
+
+
+def test_thread_safety_and_two_contexts(gpu_ctx):
+    """PEPR calls from `tree_threads` Java threads concurrently (PhylogenomicPipeline2.java:
+    1233-1254): calls on one context serialise, several contexts coexist, results are unchanged."""
+    import threading
+    from pepr_amd import engine
+    genes = [synth.simulate_alignment(8 + i, 150, 700 + i) for i in range(6)]
+    seq = [gpu_ctx.score([(g[0], g[1])], [g[2]], alpha=0.7)[0]["lnl"] for g in genes]
+    out = [None] * 6
+    ctx2 = engine.Context(0)
+    def work(i):
+        c = gpu_ctx if i % 2 == 0 else ctx2
+        for _ in range(5):
+            out[i] = c.score([(genes[i][0], genes[i][1])], [genes[i][2]], alpha=0.7)[0]["lnl"]
+    th = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert out == seq
+    ctx2.close()
+
