@@ -135,9 +135,9 @@ int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *con
         total += align_up((size_t)mp * 8, 256);                        // weight
         total += (size_t)(G.slot_cap + NSCRATCH) * CLV_ROWS * mp * 8;  // clv (+ scratch)
         total += align_up((size_t)(G.slot_cap + NSCRATCH) * mp * 4, 256);   // scalers
-        total += (size_t)CLV_ROWS * mp * 8;                            // sumtable
-        total += align_up((size_t)mp * 4, 256);                        // sumtable scalers
-        total += align_up((size_t)mp * 8, 256);                        // per-pattern lnL
+        total += (size_t)MAXTAIL * CLV_ROWS * mp * 8;                  // sumtables
+        total += (size_t)MAXTAIL * align_up((size_t)mp * 4, 256);      // sumtable scalers
+        total += (size_t)MAXTAIL * align_up((size_t)mp * 8, 256);      // per-pattern lnL
     }
     arena_bytes = total;
     if (hipMalloc((void **)&arena, total) != hipSuccess) {
@@ -152,16 +152,16 @@ int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *con
         G.d_weight = (double *)p; p += align_up((size_t)mp * 8, 256);
         G.d_clv = (double *)p; p += (size_t)(G.slot_cap + NSCRATCH) * CLV_ROWS * mp * 8;
         G.d_scl = (int *)p; p += align_up((size_t)(G.slot_cap + NSCRATCH) * mp * 4, 256);
-        G.d_sumtab = (double *)p; p += (size_t)CLV_ROWS * mp * 8;
-        G.d_sumscl = (int *)p; p += align_up((size_t)mp * 4, 256);
-        G.d_patlnl = (double *)p;
+        for (int k = 0; k < MAXTAIL; ++k) { G.d_sumtab[k] = (double *)p; p += (size_t)CLV_ROWS * mp * 8; }
+        for (int k = 0; k < MAXTAIL; ++k) { G.d_sumscl[k] = (int *)p; p += align_up((size_t)mp * 4, 256); }
+        for (int k = 0; k < MAXTAIL; ++k) { G.d_patlnl[k] = (double *)p; p += align_up((size_t)mp * 8, 256); }
         HIPCHK(hipMemcpyAsync(G.d_codes, G.aln.codes.data(), (size_t)nt * mp, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(G.d_weight, G.aln.weight.data(), (size_t)mp * 8, hipMemcpyHostToDevice, ctx->stream));
         set_alpha(g, alpha);
     }
     // results (8 doubles per gene) are written by the kernels straight into mapped pinned host
     // memory: no device-to-host copy node per step
-    HIPCHK(hipHostMalloc((void **)&h_scalars, sizeof(double) * 8 * n, hipHostMallocMapped));
+    HIPCHK(hipHostMalloc((void **)&h_scalars, sizeof(double) * 8 * MAXTAIL * n, hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void **)&d_scalars, h_scalars, 0));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -337,11 +337,11 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         return 0;
     };
 
-    // tails by gene (at most one per gene per run)
-    std::vector<int> tail_of(ngenes, -1);
+    // tails by gene, in submission order (<= MAXTAIL per gene per run)
+    std::vector<std::vector<int>> tails_of(ngenes);
     for (size_t i = 0; i < ntail; ++i) {
-        if (tail_of[tails[i].gene] >= 0) return ctx->fail(-1, "internal: two tails for one gene");
-        tail_of[tails[i].gene] = (int)i;
+        if (tails[i].slot < 0 || tails[i].slot >= MAXTAIL) return ctx->fail(-1, "internal: bad tail slot");
+        tails_of[tails[i].gene].push_back((int)i);
     }
     size_t nout = 0, nruns = 0, ie = 0, in = 0, ireq = 0, iop = 0;
     last_src.clear();
@@ -349,12 +349,54 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     double algo_bytes = 0;
     for (size_t g = 0; g < ngenes; ++g) {
         const bool has_ops = iop < nops && ops[iop].gene == (int)g;
-        if (!has_ops && tail_of[g] < 0) continue;
+        if (!has_ops && tails_of[g].empty()) continue;
         Gene &G = genes[g];
         const int mp = G.aln.mpad;
         GeneRun &run = hruns[nruns++];
         run.op_begin = (int)nout;
         max_mpad = std::max(max_mpad, mp);
+        auto emit_tail = [&](const Tail &t) -> int {
+            NvOp &d = hops[nout++];
+            std::memset(&d, 0, sizeof d);
+            bool lt, rt;
+            if (side(G, t.a, d.left, d.l_scl, lt) || side(G, t.b, d.right, d.r_scl, rt))
+                return ctx->fail(-5, "internal: tail message has no slot");
+            d.flags = (lt ? 1 : 0) | (rt ? 2 : 0); d.mpad = mp; d.mode = t.mode;
+            double *result = d_scalars + 8 * (g * MAXTAIL + t.slot);
+            if (t.mode == MODE_EVALUATE) {
+                PmatReq &r = hreq[ireq];
+                r.t = t.t0; std::memcpy(r.rates, G.rates, sizeof r.rates); r.fold_pi = 1; r.pad = 0;
+                last_src.push_back({(int)g, 0, 0, 1});          // root evaluation: branch above taxon 0
+                d.pl = d.pr = d_frags + ireq * PFRAG; ireq++;
+                d.out = G.d_patlnl[t.slot]; d.out_scl = nullptr;
+                ReduceReq &rr = hred[ie++];
+                rr.patlnl = G.d_patlnl[t.slot]; rr.weight = G.d_weight; rr.out = result; rr.mpad = mp; rr.pad = 0;
+                algo_bytes += (double)G.aln.npat * ((lt ? 1 : 640) + (rt ? 1 : 640) + 8);
+            } else {
+                d.pl = eig; d.pr = eig + PFRAG;
+                d.out = G.d_sumtab[t.slot]; d.out_scl = G.d_sumscl[t.slot];
+                d.aux = d_nsync + (size_t)in * NEWTON_SYNC_DOUBLES;
+                NewtonReq &nr = hnewt[in];
+                nr.sumtab = G.d_sumtab[t.slot]; nr.weight = G.d_weight; nr.scl = G.d_sumscl[t.slot];
+                std::memcpy(nr.rates, G.rates, sizeof nr.rates);
+                nr.t0 = t.t0; nr.tol = newton_tol; nr.out = result; nr.mpad = mp; nr.max_iter = t.max_iter;
+                nr.sync = d_nsync + (size_t)in * NEWTON_SYNC_DOUBLES; newton_maxm = std::max(newton_maxm, mp);
+                algo_bytes += (double)G.aln.npat * ((lt ? 1 : 640) + (rt ? 1 : 640) + 640);
+                in++;
+            }
+            return 0;
+        };
+        size_t ti = 0; int emitted = 0;
+        auto flush_tails = [&](bool all) -> int {
+            while (ti < tails_of[g].size()) {
+                const Tail &t = tails[tails_of[g][ti]];
+                if (!all && (t.after < 0 || t.after > emitted)) break;
+                if (int rc = emit_tail(t)) return rc;
+                ++ti;
+            }
+            return 0;
+        };
+        if (int rc = flush_tails(false)) return rc;
         for (; iop < nops && ops[iop].gene == (int)g; ++iop) {
             PendingOp &o = ops[iop];
             const int s = o.out_kind == SIDE_MSG ? slot_for(G, o.out_id) : G.slot_cap + o.out_id;
@@ -382,37 +424,10 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
                 } else last_src.push_back({(int)g, -1, 0, 0});
             }
             algo_bytes += (double)G.aln.npat * ((lt ? 1 : 640) + (rt ? 1 : 640) + 640);
+            ++emitted;
+            if (int rc = flush_tails(false)) return rc;
         }
-        if (tail_of[g] >= 0) {
-            const Tail &t = tails[tail_of[g]];
-            NvOp &d = hops[nout++];
-            std::memset(&d, 0, sizeof d);
-            bool lt, rt;
-            if (side(G, t.a, d.left, d.l_scl, lt) || side(G, t.b, d.right, d.r_scl, rt))
-                return ctx->fail(-5, "internal: tail message has no slot");
-            d.flags = (lt ? 1 : 0) | (rt ? 2 : 0); d.mpad = mp; d.mode = t.mode;
-            if (t.mode == MODE_EVALUATE) {
-                PmatReq &r = hreq[ireq];
-                r.t = t.t0; std::memcpy(r.rates, G.rates, sizeof r.rates); r.fold_pi = 1; r.pad = 0;
-                last_src.push_back({(int)g, 0, 0, 1});          // root evaluation: branch above taxon 0
-                d.pl = d.pr = d_frags + ireq * PFRAG; ireq++;
-                d.out = G.d_patlnl; d.out_scl = nullptr;
-                ReduceReq &rr = hred[ie++];
-                rr.patlnl = G.d_patlnl; rr.weight = G.d_weight; rr.out = d_scalars + 8 * g; rr.mpad = mp; rr.pad = 0;
-                algo_bytes += (double)G.aln.npat * ((lt ? 1 : 640) + (rt ? 1 : 640) + 8);
-            } else {
-                d.pl = eig; d.pr = eig + PFRAG;
-                d.out = G.d_sumtab; d.out_scl = G.d_sumscl;
-                d.aux = d_nsync + (size_t)in * NEWTON_SYNC_DOUBLES;
-                NewtonReq &nr = hnewt[in];
-                nr.sumtab = G.d_sumtab; nr.weight = G.d_weight; nr.scl = G.d_sumscl;
-                std::memcpy(nr.rates, G.rates, sizeof nr.rates);
-                nr.t0 = t.t0; nr.tol = newton_tol; nr.out = d_scalars + 8 * g; nr.mpad = mp; nr.max_iter = t.max_iter;
-                nr.sync = d_nsync + (size_t)in * NEWTON_SYNC_DOUBLES; newton_maxm = std::max(newton_maxm, mp);
-                algo_bytes += (double)G.aln.npat * ((lt ? 1 : 640) + (rt ? 1 : 640) + 640);
-                in++;
-            }
-        }
+        if (int rc = flush_tails(true)) return rc;
         run.op_end = (int)nout;
     }
 
@@ -501,7 +516,7 @@ int Batch::replay_plan(double *lnl) {
     ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += t_done - t_launched;
     ctx->resolve_events();
     for (auto &o : P.outs) genes[o.first].valid[o.second] = 1;
-    for (size_t g = 0; g < genes.size(); ++g) lnl[g] = h_scalars[8 * g];
+    for (size_t g = 0; g < genes.size(); ++g) lnl[g] = res((int)g)[0];
     return 0;
 }
 
@@ -518,7 +533,7 @@ int Batch::evaluate(const std::vector<char> &active, double *lnl) {
         tails.push_back({g, msg(g, 0, r), msg(g, r, 0), MODE_EVALUATE, G.tree.len[0][0], 0});
     }
     if (int rc = run(ops, tails)) return rc;
-    for (auto &t : tails) lnl[t.gene] = h_scalars[8 * t.gene];
+    for (auto &t : tails) lnl[t.gene] = res(t.gene)[0];
     return 0;
 }
 int Batch::score(const std::vector<char> &active, double *lnl) {
@@ -539,7 +554,7 @@ int Batch::site_lnl(int g, double *out) {
     std::vector<double> l(genes.size());
     if (int rc = evaluate(act, l.data())) return rc;
     std::vector<double> pat(G.aln.mpad);
-    HIPCHK(hipMemcpy(pat.data(), G.d_patlnl, sizeof(double) * G.aln.mpad, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(pat.data(), G.d_patlnl[0], sizeof(double) * G.aln.mpad, hipMemcpyDeviceToHost));
     for (int s = 0; s < G.aln.nsites; ++s) out[s] = pat[G.aln.site2pat[s]];
     return 0;
 }
@@ -552,7 +567,7 @@ int Batch::root_derivs(double *lnl, double *d1, double *d2) {
         tails.push_back({g, msg(g, 0, r), msg(g, r, 0), MODE_SUMTABLE, G.tree.len[0][0], 0});
     }
     if (int rc = run(ops, tails)) return rc;
-    for (int g = 0; g < (int)genes.size(); ++g) { lnl[g] = h_scalars[8 * g + 1]; d1[g] = h_scalars[8 * g + 2]; d2[g] = h_scalars[8 * g + 3]; }
+    for (int g = 0; g < (int)genes.size(); ++g) { lnl[g] = res(g)[1]; d1[g] = res(g)[2]; d2[g] = res(g)[3]; }
     return 0;
 }
 
@@ -592,7 +607,7 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
         for (auto &t : tails) {
             Gene &G = genes[t.gene];
             auto [v, w] = order[t.gene][step];
-            const double nl = h_scalars[8 * t.gene], old = t.t0;
+            const double nl = res(t.gene)[0], old = t.t0;
             maxdelta[t.gene] = std::max(maxdelta[t.gene], std::fabs(nl - old));
             if (nl != old) { G.tree.set_len(v, w, nl); branch_changed(t.gene, v, w); }
         }

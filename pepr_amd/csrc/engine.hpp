@@ -11,6 +11,8 @@
 
 namespace pml {
 
+constexpr int MAXTAIL = 4;            // tail requests (evaluate / sumtable+Newton) per gene per run()
+
 enum { K_PMAT = 0, K_NEWVIEW = 1, K_EVALUATE = 2, K_SUMTABLE = 3, K_NEWTON = 4, K_REDUCE = 5, K_HOST_BUILD = 6, K_HOST_WAIT = 7, K_COUNT = 8 };
 
 struct Ctx {
@@ -48,9 +50,9 @@ struct Gene {
     double *d_weight = nullptr;
     double *d_clv = nullptr;       // slot_cap slots of 80*mpad doubles
     int *d_scl = nullptr;          // slot_cap slots of mpad ints
-    double *d_sumtab = nullptr;    // 80*mpad
-    int *d_sumscl = nullptr;       // mpad
-    double *d_patlnl = nullptr;    // mpad
+    double *d_sumtab[MAXTAIL] = {};    // 80*mpad each
+    int *d_sumscl[MAXTAIL] = {};       // mpad each
+    double *d_patlnl[MAXTAIL] = {};    // mpad each
     int slot_cap = 0, next_slot = 0;
     std::vector<int> slot_of;      // directed-edge index (v-ntax)*3+k -> slot (-1 = none)
     std::vector<uint8_t> valid;
@@ -115,7 +117,10 @@ struct Batch {
     // --- plumbing ---
     int need(int g, int v, int to, std::vector<PendingOp> &ops);   // returns level
     // run the collected newviews, then the tail ops (evaluate or sumtable+newton), one sync
-    struct Tail { int gene; Side a, b; int mode; double t0; int max_iter; };
+    // a tail is evaluated after `after` newview ops of its gene (-1 = after all of them); `slot`
+    // selects one of the gene's MAXTAIL sumtable / per-pattern-lnL / result buffers
+    struct Tail { int gene; Side a, b; int mode; double t0; int max_iter; int slot = 0; int after = -1; };
+    double *res(int g, int slot = 0) const { return h_scalars + 8 * ((size_t)g * MAXTAIL + slot); }
     Side msg(int g, int node, int toward) const;
     int run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails);
     int ensure_stage(size_t bytes);

@@ -70,32 +70,32 @@ int Batch::nni_round(const std::vector<char> &active, std::vector<double> &lnl, 
     }
     std::vector<std::vector<double>> L(n), Tn(n);
     for (int g = 0; g < n; ++g) { L[g].assign(edges[g].size() * 3, 0.0); Tn[g].assign(edges[g].size() * 3, 0.0); }
-    for (size_t step = 0; step < maxsteps; ++step) {
+    // one run() per internal edge: the current arrangement and both alternatives are three tails
+    // (slots 0..2) of the same gene; alternative k builds its end CLVs into scratch 2k-2, 2k-1
+    for (size_t step = 0; step < maxsteps / 3; ++step) {
         std::vector<PendingOp> ops; std::vector<Tail> tails;
         for (int g = 0; g < n; ++g) {
-            if (!active[g] || step >= edges[g].size() * 3) continue;
+            if (!active[g] || step >= edges[g].size()) continue;
             const Tree &T = genes[g].tree;
-            auto [u, v] = edges[g][step / 3];
-            const int alt = (int)(step % 3);
+            auto [u, v] = edges[g][step];
             const double t0 = T.len[u][T.slot(u, v)];
-            if (alt == 0) {
-                need(g, u, v, ops); need(g, v, u, ops);
-                tails.push_back({g, msg(g, u, v), msg(g, v, u), MODE_SUMTABLE, t0, 32});
-            } else {
-                int a[2], c[2]; double la[2], lc[2];
-                others(T, u, v, a, la); others(T, v, u, c, lc);
-                const int y = (alt == 1) ? 0 : 1;
-                need(g, a[0], u, ops); need(g, a[1], u, ops); need(g, c[0], v, ops); need(g, c[1], v, ops);
-                PendingOp X; X.gene = g; X.out_kind = SIDE_SCRATCH; X.out_id = 0; X.level = 0;
+            int a[2], c[2]; double la[2], lc[2];
+            others(T, u, v, a, la); others(T, v, u, c, lc);
+            need(g, u, v, ops); need(g, v, u, ops);
+            need(g, a[0], u, ops); need(g, a[1], u, ops); need(g, c[0], v, ops); need(g, c[1], v, ops);
+            tails.push_back({g, msg(g, u, v), msg(g, v, u), MODE_SUMTABLE, t0, 32, 0, -1});
+            for (int alt = 1; alt <= 2; ++alt) {
+                const int y = (alt == 1) ? 0 : 1, sx = 2 * alt - 2, sy = 2 * alt - 1;
+                PendingOp X; X.gene = g; X.out_kind = SIDE_SCRATCH; X.out_id = sx; X.level = 0;
                 X.child[0] = msg(g, a[0], u); X.t[0] = la[0]; X.child[1] = msg(g, c[y], v); X.t[1] = lc[y];
-                PendingOp Y; Y.gene = g; Y.out_kind = SIDE_SCRATCH; Y.out_id = 1; Y.level = 0;
+                PendingOp Y; Y.gene = g; Y.out_kind = SIDE_SCRATCH; Y.out_id = sy; Y.level = 0;
                 Y.child[0] = msg(g, a[1], u); Y.t[0] = la[1]; Y.child[1] = msg(g, c[1 - y], v); Y.t[1] = lc[1 - y];
                 ops.push_back(X); ops.push_back(Y);
-                tails.push_back({g, {SIDE_SCRATCH, 0}, {SIDE_SCRATCH, 1}, MODE_SUMTABLE, t0, 32});
+                tails.push_back({g, {SIDE_SCRATCH, sx}, {SIDE_SCRATCH, sy}, MODE_SUMTABLE, t0, 32, alt, -1});
             }
         }
         if (int rc = run(ops, tails)) return rc;
-        for (auto &t : tails) { Tn[t.gene][step] = h_scalars[8 * t.gene]; L[t.gene][step] = h_scalars[8 * t.gene + 1]; }
+        for (auto &t : tails) { Tn[t.gene][3 * step + t.slot] = res(t.gene, t.slot)[0]; L[t.gene][3 * step + t.slot] = res(t.gene, t.slot)[1]; }
     }
     // candidate selection and application
     std::vector<std::vector<Cand>> cands(n);
@@ -243,20 +243,32 @@ int Batch::spr_round(const std::vector<char> &active, int radius, std::vector<do
             any = true;
             const Tree &T = genes[g].tree;
             if (S.phase == 0) {
-                const Unit &u = S.units[S.ui];
-                for (const PathOp &po : u.paths) {
-                    need_side(g, po.left, ops); need_side(g, po.right, ops);
-                    PendingOp o; o.gene = g; o.out_kind = SIDE_SCRATCH; o.out_id = po.depth; o.level = 0;
-                    o.child[0] = po.left; o.t[0] = po.tl; o.child[1] = po.right; o.t[1] = po.tr;
-                    ops.push_back(o);
+                // up to MAXTAIL consecutive candidates per run: every message they need is requested
+                // first (regular CLVs), then per candidate [path ops, insertion, evaluate tail]; the
+                // tail is placed right behind its insertion, so one insertion slot serves all
+                const size_t k1 = std::min(S.units.size(), S.ui + (size_t)MAXTAIL);
+                const Side sp = msg(g, S.s, S.p);
+                need_side(g, sp, ops);
+                for (size_t k = S.ui; k < k1; ++k) {
+                    const Unit &u = S.units[k];
+                    for (const PathOp &po : u.paths) { need_side(g, po.left, ops); need_side(g, po.right, ops); }
+                    need_side(g, msg(g, u.h, u.g), ops);
                 }
-                const double tgh = T.len[u.g][T.slot(u.g, u.h)];
-                const Side hg = msg(g, u.h, u.g), sp = msg(g, S.s, S.p);
-                need_side(g, hg, ops); need_side(g, sp, ops);
-                PendingOp I; I.gene = g; I.out_kind = SIDE_SCRATCH; I.out_id = SPR_INS_SLOT; I.level = 0;
-                I.child[0] = {SIDE_SCRATCH, u.mslot}; I.t[0] = 0.5 * tgh; I.child[1] = hg; I.t[1] = 0.5 * tgh;
-                ops.push_back(I);
-                tails.push_back({g, sp, {SIDE_SCRATCH, SPR_INS_SLOT}, MODE_EVALUATE, S.ts, 0});
+                int count = 0;
+                for (size_t q = 0; q < ops.size(); ++q) if (ops[q].gene == g) ++count;
+                for (size_t k = S.ui; k < k1; ++k) {
+                    const Unit &u = S.units[k];
+                    for (const PathOp &po : u.paths) {
+                        PendingOp o; o.gene = g; o.out_kind = SIDE_SCRATCH; o.out_id = po.depth; o.level = 0;
+                        o.child[0] = po.left; o.t[0] = po.tl; o.child[1] = po.right; o.t[1] = po.tr;
+                        ops.push_back(o); ++count;
+                    }
+                    const double tgh = T.len[u.g][T.slot(u.g, u.h)];
+                    PendingOp I; I.gene = g; I.out_kind = SIDE_SCRATCH; I.out_id = SPR_INS_SLOT; I.level = 0;
+                    I.child[0] = {SIDE_SCRATCH, u.mslot}; I.t[0] = 0.5 * tgh; I.child[1] = msg(g, u.h, u.g); I.t[1] = 0.5 * tgh;
+                    ops.push_back(I); ++count;
+                    tails.push_back({g, sp, {SIDE_SCRATCH, SPR_INS_SLOT}, MODE_EVALUATE, S.ts, 0, (int)(k - S.ui), count});
+                }
                 kind[g] = 0;
             } else if (S.phase >= 1 && S.phase <= 4) {
                 int u, v;
@@ -277,11 +289,16 @@ int Batch::spr_round(const std::vector<char> &active, int radius, std::vector<do
         for (int g = 0; g < n; ++g) {
             if (kind[g] < 0) continue;
             SprState &S = st[g]; Tree &T = genes[g].tree;
-            const double r0 = h_scalars[8 * g];
+            const double r0 = res(g)[0];
             if (kind[g] == 0) {
-                const Unit &u = S.units[S.ui];
-                if (r0 > S.best) { S.best = r0; S.bg = u.g; S.bh = u.h; }
-                if (++S.ui < S.units.size()) continue;
+                const size_t k1 = std::min(S.units.size(), S.ui + (size_t)MAXTAIL);
+                for (size_t k = S.ui; k < k1; ++k) {
+                    const Unit &u = S.units[k];
+                    const double sc = res(g, (int)(k - S.ui))[0];
+                    if (sc > S.best) { S.best = sc; S.bg = u.g; S.bh = u.h; }
+                }
+                S.ui = k1;
+                if (S.ui < S.units.size()) continue;
                 if (S.bg >= 0 && S.best > lnl[g] + SPR_MIN_GAIN) {
                     S.backup = T;
                     spr_apply(T, S.p, S.x, S.y, S.bg, S.bh);
