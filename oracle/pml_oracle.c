@@ -497,7 +497,8 @@ struct po_engine {
     const po_tree *bound;   /* tree the cache refers to */
     double tipvec[PO_NCODES][PO_NS];
     double *sumtab;    /* npat*K*20 */
-    double ntol;       /* Newton stop: |dt| < ntol (1e-8 fine, 1e-6 coarse phases) */
+    double ntol;       /* Newton stop: |dt| < ntol */
+    unsigned char *dirty, *dirty_next;   /* [node*3+slot]: branch needs re-optimisation (both directions set) */
     long n_newview, n_evaluate, n_deriv;
 };
 
@@ -510,6 +511,7 @@ po_engine *po_engine_create(const po_aln *a, const po_model *m, int ncat, double
     for (int c = 0; c < PO_NCODES; c++) { unsigned mk = po_code_mask(c); for (int s = 0; s < 20; s++) e->tipvec[c][s] = (mk >> s) & 1 ? 1.0 : 0.0; }
     e->sumtab = (double *)malloc(sizeof(double) * (size_t)(e->npat > 0 ? e->npat : 1) * ncat * 20);
     e->ntol = 1e-8;
+    e->dirty = (unsigned char *)calloc((size_t)e->nnodes * 3, 1); e->dirty_next = (unsigned char *)calloc((size_t)e->nnodes * 3, 1);
     po_engine_set_alpha(e, alpha);
     return e;
 }
@@ -517,7 +519,7 @@ void po_engine_free(po_engine *e) {
     if (!e) return;
     int nd = (e->nnodes - e->ntax) * 3;
     for (int i = 0; i < nd; i++) { free(e->clv[i]); free(e->scl[i]); }
-    free(e->clv); free(e->scl); free(e->valid); free(e->sumtab); free(e);
+    free(e->clv); free(e->scl); free(e->valid); free(e->sumtab); free(e->dirty); free(e->dirty_next); free(e);
 }
 static void eng_invalidate_all(po_engine *e) { memset(e->valid, 0, (size_t)(e->nnodes - e->ntax) * 3); }
 void po_engine_set_alpha(po_engine *e, double alpha) {
@@ -708,19 +710,33 @@ static double eng_newton_branch(po_engine *e, double t0, double *lnl_out) {
 }
 static void tree_set_len(po_tree *t, int u, int v, double l) { t->len[u][slot_of(t, u, v)] = l; t->len[v][slot_of(t, v, u)] = l; }
 
-static void eng_smooth_rec(po_engine *e, po_tree *t, int v, int from, double *maxdelta) {
+/* dirty-branch bookkeeping: a smoothing pass re-optimises only branches flagged dirty; a branch
+ * whose length moved by more than thr flags itself and every branch sharing a node with it for
+ * the NEXT pass (DESIGN.md "smoothing pass") */
+static void mark_node(unsigned char *f, const po_tree *t, int v) {
+    for (int k = 0; k < 3; k++) { int w = t->nbr[v][k]; if (w < 0) continue; f[v * 3 + k] = 1; f[w * 3 + slot_of(t, w, v)] = 1; }
+}
+static void mark_all(po_engine *e) { memset(e->dirty, 1, (size_t)e->nnodes * 3); }
+static void eng_smooth_rec(po_engine *e, po_tree *t, int v, int from, double *maxdelta, double thr) {
     for (int k = 0; k < 3; k++) {
         int w = t->nbr[v][k]; if (w < 0 || w == from) continue;
-        eng_sumtable(e, t, v, w, NULL);
-        double old = t->len[v][k], nl = eng_newton_branch(e, old, NULL);
-        if (fabs(nl - old) > *maxdelta) *maxdelta = fabs(nl - old);
-        if (nl != old) { tree_set_len(t, v, w, nl); eng_branch_changed(e, t, v, w); }
-        if (w >= e->ntax) eng_smooth_rec(e, t, w, v, maxdelta);
+        if (e->dirty[v * 3 + k]) {
+            eng_sumtable(e, t, v, w, NULL);
+            double old = t->len[v][k], nl = eng_newton_branch(e, old, NULL), dl = fabs(nl - old);
+            if (dl > *maxdelta) *maxdelta = dl;
+            if (nl != old) { tree_set_len(t, v, w, nl); eng_branch_changed(e, t, v, w); }
+            if (dl > thr) { mark_node(e->dirty_next, t, v); mark_node(e->dirty_next, t, w); }
+        }
+        if (w >= e->ntax) eng_smooth_rec(e, t, w, v, maxdelta, thr);
     }
 }
-/* one smoothing pass over all branches, DFS from taxon 0 */
-static double eng_smooth(po_engine *e, po_tree *t) {
-    double md = 0; eng_smooth_rec(e, t, 0, -1, &md); return md;
+/* one smoothing pass over the dirty branches, DFS from taxon 0; returns max |dt| */
+static double eng_smooth(po_engine *e, po_tree *t, double thr) {
+    double md = 0;
+    memset(e->dirty_next, 0, (size_t)e->nnodes * 3);
+    eng_smooth_rec(e, t, 0, -1, &md, thr);
+    memcpy(e->dirty, e->dirty_next, (size_t)e->nnodes * 3);
+    return md;
 }
 
 /* Brent maximisation of lnL over alpha on log scale */
@@ -757,13 +773,16 @@ double po_engine_optimize(po_engine *e, po_tree *t, int opt_alpha, double eps) {
     for (int i = 0; i < t->nnodes; i++) for (int k = 0; k < 3; k++) if (t->nbr[i][k] >= 0 && t->len[i][k] < PO_TMIN) t->len[i][k] = PO_TMIN;
     eng_invalidate_all(e);
     double lnl = po_engine_lnl(e, t, NULL);
-    /* coarse level (eps >= 0.05: the search's intermediate optimisations): <= 8 passes per round until
-     * max |dt| < 1e-3, Newton to 1e-6; fine level: <= 16 passes until 1e-6, Newton to 1e-8 */
-    const int coarse = eps >= 0.05, maxpass = coarse ? 8 : 16;
-    const double thr = coarse ? 1e-3 : 1e-6, save = e->ntol;
-    e->ntol = coarse ? 1e-6 : 1e-8;
+    /* precision follows eps: passes stop when max |dt| < thr = clamp(eps/100, 1e-6, 1e-3), Newton stops
+     * at thr/100; <= 8 passes per round for eps >= 0.05 (the search's intermediate optimisations),
+     * <= 16 otherwise; every round starts with all branches dirty */
+    const int maxpass = eps >= 0.05 ? 8 : 16;
+    double thr = eps * 0.01; if (thr < 1e-6) thr = 1e-6; if (thr > 1e-3) thr = 1e-3;
+    const double save = e->ntol;
+    e->ntol = thr * 0.01;
     for (int round = 0; round < 100; round++) {
-        for (int pass = 0; pass < maxpass; pass++) { if (eng_smooth(e, t) < thr) break; }
+        mark_all(e);
+        for (int pass = 0; pass < maxpass; pass++) { if (eng_smooth(e, t, thr) < thr) break; }
         double nl = opt_alpha ? eng_opt_alpha(e, t) : po_engine_lnl(e, t, NULL);
         double gain = nl - lnl; lnl = nl;
         if (gain < eps) break;
@@ -879,17 +898,18 @@ static void tree_swap(po_tree *t, int u, int x, int v, int y) {
     t->nbr[u][ku] = y; t->len[u][ku] = ly; t->nbr[v][kv] = x; t->len[v][kv] = lx;
     t->nbr[x][kx] = v; t->nbr[y][ky] = u;
 }
-static void nni_apply(po_tree *t, int u, int v, int alt, double tnew) {
+static void nni_apply(po_engine *e, po_tree *t, int u, int v, int alt, double tnew) {
     int a[2], c[2]; double la[2], lc[2];
     others(t, u, v, a, la); others(t, v, u, c, lc);
     tree_swap(t, u, a[1], v, alt == 1 ? c[0] : c[1]);
     tree_set_len(t, u, v, tnew);
+    mark_node(e->dirty, t, u); mark_node(e->dirty, t, v);      /* the five branches of the quartet */
 }
 static void tree_assign(po_tree *dst, const po_tree *src) {
     memcpy(dst->nbr, src->nbr, sizeof(int[3]) * src->nnodes); memcpy(dst->len, src->len, sizeof(double[3]) * src->nnodes);
 }
 static double light_smooth(po_engine *e, po_tree *t) {
-    for (int pass = 0; pass < 2; pass++) if (eng_smooth(e, t) < 1e-3) break;
+    for (int pass = 0; pass < 2; pass++) if (eng_smooth(e, t, 1e-3) < 1e-3) break;     /* dirty = around the moves */
     return po_engine_lnl(e, t, NULL);
 }
 /* one NNI round; returns number of applied moves, updates *lnl */
@@ -928,16 +948,18 @@ static int nni_round(po_engine *e, po_tree *t, double *lnl) {
         char *used = (char *)calloc(t->nnodes, 1);
         po_tree *backup = po_tree_copy(t);
         double lnl0 = *lnl;
+        memset(e->dirty, 0, (size_t)e->nnodes * 3);
         for (i = 0; i < ncand; i++) {
             if (used[cands[i].u] || used[cands[i].v]) continue;
             used[cands[i].u] = used[cands[i].v] = 1;
-            nni_apply(t, cands[i].u, cands[i].v, cands[i].alt, cands[i].t); applied++;
+            nni_apply(e, t, cands[i].u, cands[i].v, cands[i].alt, cands[i].t); applied++;
         }
         eng_invalidate_all(e);
         double l1 = light_smooth(e, t);
         if (!(l1 > lnl0 + 1e-6)) {                     /* combined moves did not help: best one only */
             tree_assign(t, backup); eng_invalidate_all(e);
-            nni_apply(t, cands[0].u, cands[0].v, cands[0].alt, cands[0].t); applied = 1;
+            memset(e->dirty, 0, (size_t)e->nnodes * 3);
+            nni_apply(e, t, cands[0].u, cands[0].v, cands[0].alt, cands[0].t); applied = 1;
             l1 = light_smooth(e, t);
             if (!(l1 > lnl0 + 1e-6)) { tree_assign(t, backup); eng_invalidate_all(e); applied = 0; l1 = lnl0; }
         }
@@ -1080,5 +1102,6 @@ double po_engine_search(po_engine *e, po_tree **t_inout, int spr_radius, double 
         if (!moves) break;
     }
     e->ntol = 1e-8;
+    e->dirty = (unsigned char *)calloc((size_t)e->nnodes * 3, 1); e->dirty_next = (unsigned char *)calloc((size_t)e->nnodes * 3, 1);
     return po_engine_optimize(e, t, 1, eps);
 }

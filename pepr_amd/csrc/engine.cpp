@@ -130,6 +130,7 @@ int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *con
         const int nt = G.aln.ntax, mp = G.aln.mpad, ndir = 3 * (nt - 2);
         G.slot_cap = score_only ? (nt - 2) : ndir;
         G.slot_of.assign(ndir, -1); G.valid.assign(ndir, 0); G.pend_level.assign(ndir, -1);
+        G.mark_all();
         off[g] = total;
         total += align_up((size_t)nt * mp, 256);                       // codes
         total += align_up((size_t)mp * 8, 256);                        // weight
@@ -524,6 +525,7 @@ int Batch::replay_plan(double *lnl) {
 // requests
 // ------------------------------------------------------------------------------------------
 int Batch::evaluate(const std::vector<char> &active, double *lnl) {
+    ++cnt_eval;
     std::vector<PendingOp> ops; std::vector<Tail> tails;
     for (int g = 0; g < (int)genes.size(); ++g) {
         if (!active.empty() && !active[g]) continue;
@@ -571,16 +573,20 @@ int Batch::root_derivs(double *lnl, double *d1, double *d2) {
     return 0;
 }
 
-// one Gauss-Seidel pass over all branches (DFS from taxon 0, oracle order: eng_smooth_rec)
-int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &maxdelta) {
+// one Gauss-Seidel pass over the dirty branches (DFS from taxon 0, oracle order: eng_smooth_rec)
+int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &maxdelta, double thr) {
     const int n = (int)genes.size();
     maxdelta.assign(n, 0.0);
-    // per-gene DFS edge order
+    // per-gene DFS edge order, restricted to dirty branches
     std::vector<std::vector<std::pair<int, int>>> order(n);
+    std::vector<std::vector<uint8_t>> next(n);
     size_t maxlen = 0;
     for (int g = 0; g < n; ++g) {
         if (!active[g]) continue;
-        const Tree &T = genes[g].tree; const int nt = T.ntax;
+        Gene &G = genes[g];
+        const Tree &T = G.tree; const int nt = T.ntax;
+        if (G.dirty.size() != (size_t)T.nnodes() * 3) G.mark_all();
+        next[g].assign((size_t)T.nnodes() * 3, 0);
         // emulate the recursion: visit(v, from): for k: edge (v,w); if inner recurse
         // (edge list fixed up-front: topology does not change during a pass)
         struct F { int v, from, k; };
@@ -588,14 +594,16 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
         while (!st.empty()) {
             F &f = st.back();
             if (f.k >= 3) { st.pop_back(); continue; }
-            const int w = T.nbr[f.v][f.k]; f.k++;
+            const int k = f.k, w = T.nbr[f.v][k]; f.k++;
             if (w < 0 || w == f.from) continue;
-            order[g].push_back({f.v, w});
+            if (G.dirty[f.v * 3 + k]) order[g].push_back({f.v, w});
             if (w >= nt) { const int fv = f.v; st.push_back({w, fv, 0}); }
         }
         maxlen = std::max(maxlen, order[g].size());
     }
+    ++cnt_passes;
     for (size_t step = 0; step < maxlen; ++step) {
+        ++cnt_smooth;
         std::vector<PendingOp> ops; std::vector<Tail> tails;
         for (int g = 0; g < n; ++g) {
             if (!active[g] || step >= order[g].size()) continue;
@@ -607,11 +615,13 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
         for (auto &t : tails) {
             Gene &G = genes[t.gene];
             auto [v, w] = order[t.gene][step];
-            const double nl = res(t.gene)[0], old = t.t0;
-            maxdelta[t.gene] = std::max(maxdelta[t.gene], std::fabs(nl - old));
+            const double nl = res(t.gene)[0], old = t.t0, dl = std::fabs(nl - old);
+            maxdelta[t.gene] = std::max(maxdelta[t.gene], dl);
             if (nl != old) { G.tree.set_len(v, w, nl); branch_changed(t.gene, v, w); }
+            if (dl > thr) { std::swap(G.dirty, next[t.gene]); G.mark_node(v); G.mark_node(w); std::swap(G.dirty, next[t.gene]); }
         }
     }
+    for (int g = 0; g < n; ++g) if (active[g]) genes[g].dirty.swap(next[g]);
     return 0;
 }
 
@@ -650,21 +660,22 @@ int Batch::optimize(bool opt_alpha_flag, double eps, double *lnl, const std::vec
     const std::vector<char> initial(active);
     std::vector<double> cur(n), nl(n), md;
     if (int rc = evaluate(active, cur.data())) return rc;
-    // coarse level (eps >= 0.05): <= 8 passes per round until max |dt| < 1e-3, Newton to 1e-6;
-    // fine level: <= 16 passes until 1e-6, Newton to 1e-8 (oracle: po_engine_optimize)
-    const bool coarse = eps >= 0.05;
-    const int maxpass = coarse ? 8 : 16;
-    const double thr = coarse ? 1e-3 : 1e-6, save_tol = newton_tol;
-    newton_tol = coarse ? 1e-6 : 1e-8;
+    // precision follows eps (oracle: po_engine_optimize): passes stop when max |dt| < thr =
+    // clamp(eps/100, 1e-6, 1e-3), Newton stops at thr/100; <= 8 passes per round for eps >= 0.05,
+    // <= 16 otherwise; every round starts with all branches dirty
+    const int maxpass = eps >= 0.05 ? 8 : 16;
+    const double thr = std::min(1e-3, std::max(1e-6, eps * 0.01)), save_tol = newton_tol;
+    newton_tol = thr * 0.01;
     struct Restore { double &r; double v; ~Restore() { r = v; } } restore{newton_tol, save_tol};
     for (int round = 0; round < 100; ++round) {
         bool any = false; for (char a : active) any |= a;
         if (!any) break;
         std::vector<char> sm(active);
+        for (int g = 0; g < n; ++g) if (sm[g]) genes[g].mark_all();
         for (int pass = 0; pass < maxpass; ++pass) {
             bool anys = false; for (char a : sm) anys |= a;
             if (!anys) break;
-            if (int rc = smooth_pass(sm, md)) return rc;
+            if (int rc = smooth_pass(sm, md, thr)) return rc;
             for (int g = 0; g < n; ++g) if (sm[g] && md[g] < thr) sm[g] = 0;
         }
         if (opt_alpha_flag) { if (int rc = opt_alpha(active, nl.data())) return rc; }

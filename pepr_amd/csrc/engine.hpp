@@ -57,6 +57,10 @@ struct Gene {
     std::vector<int> slot_of;      // directed-edge index (v-ntax)*3+k -> slot (-1 = none)
     std::vector<uint8_t> valid;
     std::vector<int> pend_level;   // scratch for collection (-1 = not pending)
+    std::vector<uint8_t> dirty;    // [node*3+slot]: branch needs re-optimisation (both directions set)
+    void mark_node(int v) { for (int k = 0; k < 3; ++k) { const int w = tree.nbr[v][k]; if (w < 0) continue; dirty[v * 3 + k] = 1; dirty[w * 3 + tree.slot(w, v)] = 1; } }
+    void mark_all() { dirty.assign((size_t)tree.nnodes() * 3, 1); }
+    void mark_none() { dirty.assign((size_t)tree.nnodes() * 3, 0); }
 };
 
 struct pml_alignment_view { int ntax, nsites; const char *const *names; const char *const *rows; };
@@ -88,6 +92,7 @@ struct Batch {
         int max_mpad = 0; double algo_bytes = 0;
         std::vector<ReqSrc> src; std::vector<std::pair<int, int>> outs;
     } plan;
+    long cnt_smooth = 0, cnt_nni = 0, cnt_spr = 0, cnt_eval = 0, cnt_passes = 0;   // run() calls by purpose (PML_TRACE)
     unsigned topo_epoch = 0;       // bumped whenever a search may change a topology
     bool score_only_batch = false;
     int replay_plan(double *lnl);
@@ -106,7 +111,9 @@ struct Batch {
     int score(const std::vector<char> &active, double *lnl);      // invalidate + evaluate
     int site_lnl(int g, double *out);
     int root_derivs(double *lnl, double *d1, double *d2);
-    int smooth_pass(const std::vector<char> &active, std::vector<double> &maxdelta);
+    // one pass over the DIRTY branches (DFS order); a branch that moves by more than thr flags itself and
+    // its neighbours for the next pass
+    int smooth_pass(const std::vector<char> &active, std::vector<double> &maxdelta, double thr);
     int opt_alpha(const std::vector<char> &active, double *lnl);
     int optimize(bool opt_alpha_flag, double eps, double *lnl, const std::vector<char> *mask = nullptr);
     int light_smooth(const std::vector<char> &active, double *lnl);

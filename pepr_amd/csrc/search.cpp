@@ -13,6 +13,8 @@
 // node, re-optimise lightly (<= 2 smoothing passes), fall back to the single best move if the
 // combination did not improve, and to no move if that fails too.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <functional>
 
 #include "engine.hpp"
@@ -49,7 +51,7 @@ int Batch::light_smooth(const std::vector<char> &active, double *lnl) {
     for (int pass = 0; pass < 2; ++pass) {
         bool any = false; for (char a : sm) any |= a;
         if (!any) break;
-        if (int rc = smooth_pass(sm, md)) return rc;
+        if (int rc = smooth_pass(sm, md, 1e-3)) return rc;              // dirty = around the moves
         for (size_t g = 0; g < sm.size(); ++g) if (sm[g] && md[g] < 1e-3) sm[g] = 0;
     }
     return evaluate(active, lnl);
@@ -73,6 +75,7 @@ int Batch::nni_round(const std::vector<char> &active, std::vector<double> &lnl, 
     // one run() per internal edge: the current arrangement and both alternatives are three tails
     // (slots 0..2) of the same gene; alternative k builds its end CLVs into scratch 2k-2, 2k-1
     for (size_t step = 0; step < maxsteps / 3; ++step) {
+        ++cnt_nni;
         std::vector<PendingOp> ops; std::vector<Tail> tails;
         for (int g = 0; g < n; ++g) {
             if (!active[g] || step >= edges[g].size()) continue;
@@ -115,10 +118,12 @@ int Batch::nni_round(const std::vector<char> &active, std::vector<double> &lnl, 
         Tree &T = genes[g].tree;
         backup[g] = T;
         std::vector<char> used(T.nnodes(), 0);
+        genes[g].mark_none();
         for (auto &c : cands[g]) {
             if (used[c.u] || used[c.v]) continue;
             used[c.u] = used[c.v] = 1;
             nni_apply(T, c.u, c.v, c.alt, c.t); applied[g]++;
+            genes[g].mark_node(c.u); genes[g].mark_node(c.v);      // the five branches of the quartet
         }
         invalidate_all(g); stageA[g] = 1;
     }
@@ -132,7 +137,9 @@ int Batch::nni_round(const std::vector<char> &active, std::vector<double> &lnl, 
         if (l1[g] > lnl0[g] + 1e-6) { lnl[g] = l1[g]; continue; }
         genes[g].tree = backup[g]; invalidate_all(g);
         const Cand &c = cands[g][0];
+        genes[g].mark_none();
         nni_apply(genes[g].tree, c.u, c.v, c.alt, c.t); applied[g] = 1;
+        genes[g].mark_node(c.u); genes[g].mark_node(c.v);
         invalidate_all(g); stageB[g] = 1; any = true;
     }
     if (any) {
@@ -285,6 +292,7 @@ int Batch::spr_round(const std::vector<char> &active, int radius, std::vector<do
             }
         }
         if (!any) break;
+        ++cnt_spr;
         if (int rc = run(ops, tails)) return rc;
         for (int g = 0; g < n; ++g) {
             if (kind[g] < 0) continue;
@@ -353,8 +361,10 @@ int Batch::search(bool nni, int spr_radius, bool opt_alpha_flag, double eps, dou
         if (int rc = optimize(opt_alpha_flag, 0.1, lnl.data(), &active)) return rc;
         for (int g = 0; g < n; ++g) if (active[g] && moves[g] == 0) active[g] = 0;
     }
+    if (getenv("PML_TRACE")) fprintf(stderr, "[pml] before final optimize: passes %ld smooth-steps %ld nni-steps %ld spr-steps %ld evals %ld\n", cnt_passes, cnt_smooth, cnt_nni, cnt_spr, cnt_eval);
     newton_tol = 1e-8;
     if (int rc = optimize(opt_alpha_flag, eps, lnl.data())) return rc;
+    if (getenv("PML_TRACE")) fprintf(stderr, "[pml] search done: passes %ld smooth-steps %ld nni-steps %ld spr-steps %ld evals %ld\n", cnt_passes, cnt_smooth, cnt_nni, cnt_spr, cnt_eval);
     for (int g = 0; g < n; ++g) lnl_out[g] = lnl[g];
     return 0;
 }
