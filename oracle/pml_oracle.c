@@ -694,6 +694,10 @@ static double eng_newton_branch(po_engine *e, double t0, double *lnl_out) {
     for (int it = 0; it < 32; it++) {
         double step = (d2 < 0) ? -d1 / d2 : (d1 > 0 ? t : -0.5 * t);
         double tn = t + step, Ln, n1, n2; int bt = 0;
+        if (fabs(step) < e->ntol && d2 < 0) {        /* converged: take the (sub-tolerance) step unevaluated */
+            t = tn < PO_TMIN ? PO_TMIN : (tn > PO_TMAX ? PO_TMAX : tn);
+            break;
+        }
         for (;;) {
             if (tn < PO_TMIN) tn = PO_TMIN; if (tn > PO_TMAX) tn = PO_TMAX;
             eng_core_derivs(e, tn, NULL, &Ln, &n1, &n2);

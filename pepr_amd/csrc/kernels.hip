@@ -438,6 +438,10 @@ __global__ __launch_bounds__(256) void k_newton(const ModelDev *__restrict__ md,
         const double step = (d2 < 0.0) ? -d1 / d2 : (d1 > 0.0 ? t : -0.5 * t);
         double tn = t + step, Ln, n1, n2;
         int bt = 0;
+        if (fabs(step) < r.tol && d2 < 0.0) {       // converged: take the (sub-tolerance) step unevaluated
+            t = tn < PML_TMIN ? PML_TMIN : (tn > PML_TMAX ? PML_TMAX : tn);
+            break;
+        }
         for (;;) {
             tn = tn < PML_TMIN ? PML_TMIN : (tn > PML_TMAX ? PML_TMAX : tn);
             eval_at(tn, Ln, n1, n2);
@@ -487,7 +491,7 @@ void launch_reduce(const ReduceReq *reqs, int n, hipStream_t s) {
 }
 void launch_newton(const ModelDev *model, const NewtonReq *reqs, int n, int max_mpad, hipStream_t s) {
     if (n <= 0) return;
-    int S = max_mpad / 256;
+    int S = max_mpad / 128;
     S = S < 1 ? 1 : (S > NEWTON_MAX_SPLIT ? NEWTON_MAX_SPLIT : S);
     const int chunk = 1024 / S;          // S * chunk workgroups of 256 threads are co-resident on 256 CUs
     for (int off = 0; off < n; off += chunk) {
