@@ -1,5 +1,6 @@
 // api.cpp -- the C ABI declared in include/peprml.h.  Nothing here computes likelihoods on the
 // CPU: every numeric result comes from the HIP kernels; without a device pml_create() fails.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -169,18 +170,18 @@ int pml_batch_newick(pml_batch *b, int g, int digits, char **out) {
 // ---- one-shot wrappers --------------------------------------------------------------------
 enum { OP_SCORE, OP_OPTIMIZE, OP_SEARCH };
 
-static int oneshot(pml_ctx *ctx, int op, int n, const pml_alignment *alns, const char *const *newicks,
-                   const pml_model *model, const pml_search_opts *opts, int flags, pml_result *out) {
-    if (!ctx || !alns || !out || n <= 0) return PML_EINVAL;
-    for (int i = 0; i < n; ++i) std::memset(&out[i], 0, sizeof(pml_result));
-    if (op != OP_SEARCH) {
-        if (!newicks) return ctx->c.fail(PML_EINVAL, "newick required");
-        for (int i = 0; i < n; ++i) if (!newicks[i]) return ctx->c.fail(PML_EINVAL, "newick required");
-    }
-    std::lock_guard<std::mutex> lk(ctx->c.mu);
+// upper bound of the HBM a gene needs in a batch (patterns <= columns)
+static size_t gene_bytes_bound(const pml_alignment &a, bool score_only) {
+    const size_t mp = ((size_t)std::max(a.nsites, 1) + 31) / 32 * 32, nt = (size_t)std::max(a.ntax, 3);
+    const size_t slots = (score_only ? nt - 2 : 3 * (nt - 2)) + NSCRATCH + MAXTAIL;
+    return slots * CLV_ROWS * mp * 8 + slots * mp * 4 + nt * mp + 64 * mp + (1 << 16);
+}
+
+static int oneshot_chunk(pml_ctx *ctx, int op, int n, const pml_alignment *alns, const char *const *newicks,
+                         const pml_model *model, const pml_search_opts *opts, int flags, pml_result *out) {
     pml_batch *b = nullptr;
     int rc = batch_create_impl(ctx, n, alns, newicks, model, op == OP_SCORE, &b);
-    if (rc) { for (int i = 0; i < n; ++i) out[i].status = rc; return rc; }
+    if (rc) return rc;
     std::vector<double> lnl(n);
     try {
         if (op == OP_SCORE) rc = b->b.score(std::vector<char>(), lnl.data());
@@ -204,6 +205,36 @@ static int oneshot(pml_ctx *ctx, int op, int n, const pml_alignment *alns, const
     } catch (const std::bad_alloc &) { rc = ctx->c.fail(PML_ENOMEM, "host allocation failed"); }
     catch (const std::exception &e) { rc = ctx->c.fail(PML_EINVAL, e.what()); }
     b->b.destroy(); delete b;
+    return rc;
+}
+
+// one-shot batched call; gene lists that do not fit in free HBM at once are processed in
+// consecutive sub-batches (e.g. BASELINE config C5: 250 genes x 500 taxa x 2000 sites per GPU)
+static int oneshot(pml_ctx *ctx, int op, int n, const pml_alignment *alns, const char *const *newicks,
+                   const pml_model *model, const pml_search_opts *opts, int flags, pml_result *out) {
+    if (!ctx || !alns || !out || n <= 0) return PML_EINVAL;
+    for (int i = 0; i < n; ++i) std::memset(&out[i], 0, sizeof(pml_result));
+    if (op != OP_SEARCH) {
+        if (!newicks) return ctx->c.fail(PML_EINVAL, "newick required");
+        for (int i = 0; i < n; ++i) if (!newicks[i]) return ctx->c.fail(PML_EINVAL, "newick required");
+    }
+    std::lock_guard<std::mutex> lk(ctx->c.mu);
+    size_t free_b = 0, total_b = 0;
+    hipSetDevice(ctx->c.device);
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)1 << 40;
+    size_t budget = (size_t)(0.85 * (double)free_b);
+    if (const char *e = std::getenv("PML_HBM_BUDGET_MB")) budget = (size_t)std::atoll(e) << 20;   // test hook
+    int rc = 0, begin = 0;
+    while (begin < n && !rc) {
+        size_t used = 0; int end = begin;
+        while (end < n) {
+            const size_t need = gene_bytes_bound(alns[end], op == OP_SCORE);
+            if (end > begin && used + need > budget) break;
+            used += need; ++end;
+        }
+        rc = oneshot_chunk(ctx, op, end - begin, alns + begin, newicks ? newicks + begin : nullptr, model, opts, flags, out + begin);
+        begin = end;
+    }
     for (int i = 0; i < n; ++i) out[i].status = rc;
     return rc;
 }

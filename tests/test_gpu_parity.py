@@ -317,3 +317,20 @@ def test_thread_safety_and_two_contexts(gpu_ctx):
     assert out == seq
     ctx2.close()
 
+
+
+def test_oneshot_sub_batching(gpu_ctx, monkeypatch):
+    """gene lists larger than free HBM are processed in consecutive sub-batches (config C5 scale);
+    forced here with a tiny budget: results must equal the single-batch results"""
+    genes = [synth.simulate_alignment(10 + i, 200 + 30 * i, 800 + i) for i in range(7)]
+    G = [(g[0], g[1]) for g in genes]; NW = [g[2] for g in genes]
+    ref = gpu_ctx.optimize(G, NW, alpha=1.0, epsilon=1e-4)
+    monkeypatch.setenv("PML_HBM_BUDGET_MB", "40")          # one 12x260 gene needs ~12 MB in full mode
+    out = gpu_ctx.optimize(G, NW, alpha=1.0, epsilon=1e-4)
+    for a, b in zip(ref, out):
+        assert a["lnl"] == b["lnl"] and a["alpha"] == b["alpha"] and a["newick"] == b["newick"]
+    sc = gpu_ctx.score(G, NW, alpha=0.7, site_lnl=True)
+    monkeypatch.delenv("PML_HBM_BUDGET_MB")
+    sc2 = gpu_ctx.score(G, NW, alpha=0.7, site_lnl=True)
+    for a, b in zip(sc, sc2):
+        assert a["lnl"] == b["lnl"] and np.array_equal(a["site_lnl"], b["site_lnl"])
