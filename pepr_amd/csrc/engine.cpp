@@ -97,6 +97,7 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *const *newicks, int pm, int nc,
                   double alpha, bool score_only) {
     ctx = c; pi_mode = pm; ncat = nc; score_only_batch = score_only;
+    virtual_cherries = std::getenv("PML_NO_CHERRY") == nullptr;
     if (n <= 0) return ctx->fail(-1, "empty batch");
     if (nc != 1 && nc != 4) return ctx->fail(-1, "ncat must be 1 or 4");
     if (int rc = ctx->ensure_model(pm)) return rc;
@@ -200,7 +201,7 @@ int Batch::ensure_frags(size_t sets) {
     const size_t cap = std::max(sets * 5 / 4, (size_t)256);
     if (d_frags) hipFree(d_frags);
     d_frags = nullptr; frag_cap = 0; plan.valid = false;      // cached descriptors point into d_frags
-    HIPCHK(hipMalloc((void **)&d_frags, cap * PFRAG * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&d_frags, cap * FRAG_STRIDE * sizeof(double)));
     frag_cap = cap;
     return 0;
 }
@@ -245,16 +246,24 @@ int Batch::slot_for(Gene &G, int idx) {
 // ------------------------------------------------------------------------------------------
 // lazy collection of the newviews a message depends on
 // ------------------------------------------------------------------------------------------
+bool Batch::is_cherry(int g, int node, int toward) const {
+    const Gene &G = genes[g];
+    const int nt = G.aln.ntax;
+    if (!virtual_cherries || node < nt) return false;
+    for (int k = 0; k < 3; ++k) { const int w = G.tree.nbr[node][k]; if (w != toward && w >= nt) return false; }
+    return true;
+}
 Side Batch::msg(int g, int node, int toward) const {
     const Gene &G = genes[g];
     if (node < G.aln.ntax) return {SIDE_TIP, node};
-    return {SIDE_MSG, (node - G.aln.ntax) * 3 + G.tree.slot(node, toward)};
+    const int idx = (node - G.aln.ntax) * 3 + G.tree.slot(node, toward);
+    return {is_cherry(g, node, toward) ? SIDE_CHERRY : SIDE_MSG, idx};
 }
 
 int Batch::need(int g, int v, int to, std::vector<PendingOp> &ops) {
     Gene &G = genes[g];
     const int nt = G.aln.ntax;
-    if (v < nt) return 0;
+    if (v < nt || is_cherry(g, v, to)) return 0;
     // explicit stack (trees can be caterpillars of depth ~ntax)
     struct Frame { int v, to, k, stage, lv[2]; };
     std::vector<Frame> st;
@@ -273,7 +282,7 @@ int Batch::need(int g, int v, int to, std::vector<PendingOp> &ops) {
         if (f.stage < 2) {
             const int c = ch[f.stage];
             f.stage++;
-            if (c < nt) { ret = 0; continue; }            // tip child: level 0, stay in this frame
+            if (c < nt || is_cherry(g, c, f.v)) { ret = 0; continue; }   // tip / virtual cherry child: nothing to compute
             const int fv = f.v;
             st.push_back({c, fv, G.tree.slot(c, fv), 0, {0, 0}});
             continue;
@@ -304,8 +313,8 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     const size_t nops = ops.size(), ntail = tails.size();
     size_t neval = 0, nnewton = 0;
     for (auto &t : tails) { if (t.mode == MODE_EVALUATE) neval++; else nnewton++; }
-    const size_t nreq = 2 * nops + neval;
-    if (int rc = ensure_frags(std::max(nreq, (size_t)1))) return rc;
+    const size_t nreq_max = 6 * nops + 5 * ntail;          // <= 3 requests per side
+    if (int rc = ensure_frags(std::max(nreq_max, (size_t)1))) return rc;
     if (nnewton > nsync_cap) {
         if (d_nsync) hipFree(d_nsync);
         d_nsync = nullptr; nsync_cap = 0;
@@ -315,7 +324,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     }
     const size_t ngenes = genes.size();
     const size_t o_req = 0;
-    const size_t o_ops = align_up(o_req + nreq * sizeof(PmatReq), 256);
+    const size_t o_ops = align_up(o_req + nreq_max * sizeof(PmatReq), 256);
     const size_t o_runs = align_up(o_ops + (nops + ntail) * sizeof(NvOp), 256);
     const size_t o_red = align_up(o_runs + ngenes * sizeof(GeneRun), 256);
     const size_t o_newt = align_up(o_red + neval * sizeof(ReduceReq), 256);
@@ -329,12 +338,40 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     NewtonReq *hnewt = (NewtonReq *)(hs + o_newt);
     const double *eig = ctx->d_eigfrags[pi_mode];
 
-    auto side = [&](Gene &G, const Side &sd, const void *&ptr, const int *&scl, bool &tip) {
-        const int mp = G.aln.mpad;
-        if (sd.kind == SIDE_TIP) { ptr = G.d_codes + (size_t)sd.id * mp; scl = nullptr; tip = true; return 0; }
-        const int s = sd.kind == SIDE_MSG ? G.slot_of[sd.id] : G.slot_cap + sd.id;
-        if (s < 0) return -1;
-        ptr = G.d_clv + (size_t)s * CLV_ROWS * mp; scl = G.d_scl + (size_t)s * mp; tip = false;
+    size_t nout = 0, nruns = 0, ie = 0, in = 0, ireq = 0, iop = 0;
+    last_src.clear();
+    int max_mpad = 0, newton_maxm = 0;
+    double algo_bytes = 0;
+    // one transition-matrix request (fragment set or tip table) for branch (v, slot q) of gene g
+    auto add_req = [&](size_t g, double t, int kind, int v, int q) -> const double * {
+        PmatReq &r = hreq[ireq];
+        r.t = t; std::memcpy(r.rates, genes[g].rates, sizeof r.rates); r.kind = kind; r.pad = 0;
+        last_src.push_back({(int)g, v, q, kind});
+        return d_frags + (ireq++) * FRAG_STRIDE;
+    };
+    // resolves one side of an op: pointers, kind, scaling counts; `want_table`: newview tip sides look
+    // their contraction up in a tip table; `t_branch`/(bv,bq): the branch between this side and the op
+    // node (fragment request), unless the caller supplies fixed matrices
+    struct Resolved { OpSide s; int kind; const int *scl; double bytes; };
+    auto resolve = [&](size_t g, const Side &sd, Resolved &R) -> int {
+        Gene &G = genes[g];
+        const int mp = G.aln.mpad, nt = G.aln.ntax;
+        R.s = OpSide{nullptr, nullptr, nullptr, nullptr}; R.scl = nullptr;
+        if (sd.kind == SIDE_TIP) { R.kind = SK_TIP; R.s.p0 = G.d_codes + (size_t)sd.id * mp; R.bytes = 1; return 0; }
+        if (sd.kind == SIDE_CHERRY) {
+            const int v = nt + sd.id / 3, k = sd.id % 3;
+            int tips[2], qs[2], ci = 0;
+            for (int q = 0; q < 3; ++q) if (q != k) { tips[ci] = G.tree.nbr[v][q]; qs[ci] = q; ++ci; }
+            R.kind = SK_CHERRY;
+            R.s.p0 = G.d_codes + (size_t)tips[0] * mp; R.s.p1 = G.d_codes + (size_t)tips[1] * mp;
+            R.s.t0 = add_req(g, G.tree.len[v][qs[0]], PM_TIPTABLE, v, qs[0]);
+            R.s.t1 = add_req(g, G.tree.len[v][qs[1]], PM_TIPTABLE, v, qs[1]);
+            R.bytes = 640 + 642;       // SURVEY 8d accounting: the tip-tip newview (642 B) + reading its CLV (640 B)
+            return 0;
+        }
+        const int slot = sd.kind == SIDE_MSG ? G.slot_of[sd.id] : G.slot_cap + sd.id;
+        if (slot < 0) return -1;
+        R.kind = SK_CLV; R.s.p0 = G.d_clv + (size_t)slot * CLV_ROWS * mp; R.scl = G.d_scl + (size_t)slot * mp; R.bytes = 640;
         return 0;
     };
 
@@ -344,10 +381,6 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         if (tails[i].slot < 0 || tails[i].slot >= MAXTAIL) return ctx->fail(-1, "internal: bad tail slot");
         tails_of[tails[i].gene].push_back((int)i);
     }
-    size_t nout = 0, nruns = 0, ie = 0, in = 0, ireq = 0, iop = 0;
-    last_src.clear();
-    int max_mpad = 0, newton_maxm = 0;
-    double algo_bytes = 0;
     for (size_t g = 0; g < ngenes; ++g) {
         const bool has_ops = iop < nops && ops[iop].gene == (int)g;
         if (!has_ops && tails_of[g].empty()) continue;
@@ -359,20 +392,17 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         auto emit_tail = [&](const Tail &t) -> int {
             NvOp &d = hops[nout++];
             std::memset(&d, 0, sizeof d);
-            bool lt, rt;
-            if (side(G, t.a, d.left, d.l_scl, lt) || side(G, t.b, d.right, d.r_scl, rt))
-                return ctx->fail(-5, "internal: tail message has no slot");
-            d.flags = (lt ? 1 : 0) | (rt ? 2 : 0); d.mpad = mp; d.mode = t.mode;
+            Resolved L, R;
+            if (resolve(g, t.a, L) || resolve(g, t.b, R)) return ctx->fail(-5, "internal: tail message has no slot");
+            d.l = L.s; d.r = R.s; d.l_scl = L.scl; d.r_scl = R.scl;
+            d.flags = L.kind | (R.kind << 2); d.mpad = mp; d.mode = t.mode;
             double *result = d_scalars + 8 * (g * MAXTAIL + t.slot);
             if (t.mode == MODE_EVALUATE) {
-                PmatReq &r = hreq[ireq];
-                r.t = t.t0; std::memcpy(r.rates, G.rates, sizeof r.rates); r.fold_pi = 1; r.pad = 0;
-                last_src.push_back({(int)g, 0, 0, 1});          // root evaluation: branch above taxon 0
-                d.pl = d.pr = d_frags + ireq * PFRAG; ireq++;
+                d.pl = d.pr = add_req(g, t.t0, PM_FRAGS_PI, t.bv, t.bq);
                 d.out = G.d_patlnl[t.slot]; d.out_scl = nullptr;
                 ReduceReq &rr = hred[ie++];
                 rr.patlnl = G.d_patlnl[t.slot]; rr.weight = G.d_weight; rr.out = result; rr.mpad = mp; rr.pad = 0;
-                algo_bytes += (double)G.aln.npat * ((lt ? 1 : 640) + (rt ? 1 : 640) + 8);
+                algo_bytes += (double)G.aln.npat * (L.bytes + R.bytes + 8);
             } else {
                 d.pl = eig; d.pr = eig + PFRAG;
                 d.out = G.d_sumtab[t.slot]; d.out_scl = G.d_sumscl[t.slot];
@@ -382,7 +412,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
                 std::memcpy(nr.rates, G.rates, sizeof nr.rates);
                 nr.t0 = t.t0; nr.tol = newton_tol; nr.out = result; nr.mpad = mp; nr.max_iter = t.max_iter;
                 nr.sync = d_nsync + (size_t)in * NEWTON_SYNC_DOUBLES; newton_maxm = std::max(newton_maxm, mp);
-                algo_bytes += (double)G.aln.npat * ((lt ? 1 : 640) + (rt ? 1 : 640) + 640);
+                algo_bytes += (double)G.aln.npat * (L.bytes + R.bytes + 640);
                 in++;
             }
             return 0;
@@ -407,24 +437,23 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             d.mode = MODE_NEWVIEW;
             d.out = G.d_clv + (size_t)s * CLV_ROWS * mp;
             d.out_scl = G.d_scl + (size_t)s * mp;
-            bool lt, rt;
-            if (side(G, o.child[0], d.left, d.l_scl, lt) || side(G, o.child[1], d.right, d.r_scl, rt))
-                return ctx->fail(-5, "internal: child message has no slot");
-            d.flags = (lt ? 1 : 0) | (rt ? 2 : 0);
+            Resolved S[2];
+            if (resolve(g, o.child[0], S[0]) || resolve(g, o.child[1], S[1])) return ctx->fail(-5, "internal: child message has no slot");
             d.mpad = mp;
-            d.pl = d_frags + ireq * PFRAG; d.pr = d_frags + (ireq + 1) * PFRAG;
+            d.flags = S[0].kind | (S[1].kind << 2);
+            const double *pm[2];
             for (int c = 0; c < 2; ++c) {
-                PmatReq &r = hreq[ireq++];
-                r.t = o.t[c]; std::memcpy(r.rates, G.rates, sizeof r.rates); r.fold_pi = 0; r.pad = 0;
-                // remember where this branch length lives (plan replay): message o.out_id = (v, k), child c
+                // where this child's branch length lives (plan replay): output message (v, k), child c
+                int bv = -1, bq = 0;
                 if (o.out_kind == SIDE_MSG) {
-                    const int v = G.aln.ntax + o.out_id / 3, k = o.out_id % 3;
-                    int q = 0, seen = 0;
-                    for (; q < 3; ++q) if (q != k) { if (seen == c) break; ++seen; }
-                    last_src.push_back({(int)g, v, q, 0});
-                } else last_src.push_back({(int)g, -1, 0, 0});
+                    bv = G.aln.ntax + o.out_id / 3; const int k = o.out_id % 3;
+                    int seen = 0;
+                    for (bq = 0; bq < 3; ++bq) if (bq != k) { if (seen == c) break; ++seen; }
+                }
+                pm[c] = add_req(g, o.t[c], PM_FRAGS, bv, bq);
             }
-            algo_bytes += (double)G.aln.npat * ((lt ? 1 : 640) + (rt ? 1 : 640) + 640);
+            d.l = S[0].s; d.r = S[1].s; d.l_scl = S[0].scl; d.r_scl = S[1].scl; d.pl = pm[0]; d.pr = pm[1];
+            algo_bytes += (double)G.aln.npat * (S[0].bytes + S[1].bytes + 640);
             ++emitted;
             if (int rc = flush_tails(false)) return rc;
         }
@@ -494,7 +523,7 @@ int Batch::replay_plan(double *lnl) {
     for (size_t i = 0; i < P.nreq; ++i) {
         const ReqSrc &s = P.src[i];
         const Gene &G = genes[s.gene];
-        hreq[i].t = s.fold ? G.tree.len[0][0] : G.tree.len[s.v][s.q];
+        hreq[i].t = G.tree.len[s.v][s.q];
         std::memcpy(hreq[i].rates, G.rates, sizeof hreq[i].rates);
     }
     char *ds = (char *)P.d;
@@ -532,7 +561,7 @@ int Batch::evaluate(const std::vector<char> &active, double *lnl) {
         Gene &G = genes[g];
         const int r = G.tree.nbr[0][0];
         need(g, r, 0, ops);
-        tails.push_back({g, msg(g, 0, r), msg(g, r, 0), MODE_EVALUATE, G.tree.len[0][0], 0});
+        tails.push_back({g, msg(g, 0, r), msg(g, r, 0), MODE_EVALUATE, G.tree.len[0][0], 0, 0, -1, 0, 0});
     }
     if (int rc = run(ops, tails)) return rc;
     for (auto &t : tails) lnl[t.gene] = res(t.gene)[0];

@@ -66,8 +66,10 @@ struct Gene {
 struct pml_alignment_view { int ntax, nsites; const char *const *names; const char *const *rows; };
 
 constexpr int NSCRATCH = 8;          // extra CLV slots per gene for candidate evaluation (NNI / SPR)
-enum { SIDE_TIP = 0, SIDE_MSG = 1, SIDE_SCRATCH = 2 };
-struct Side { int kind, id; };       // tip node id | directed-edge index (v-ntax)*3+k | scratch slot
+enum { SIDE_TIP = 0, SIDE_MSG = 1, SIDE_SCRATCH = 2, SIDE_CHERRY = 3 };
+// tip node id | directed-edge index (v-ntax)*3+k | scratch slot | directed-edge index of a message whose
+// two children are tips ("cherry": never materialised, recomputed from two tip tables where consumed)
+struct Side { int kind, id; };
 struct PendingOp { int gene, out_kind, out_id, level; Side child[2]; double t[2]; };
 
 struct Batch {
@@ -84,7 +86,7 @@ struct Batch {
     double *d_nsync = nullptr; size_t nsync_cap = 0;             // Newton inter-workgroup sync blocks
     // cached descriptors of the full-traversal score of ALL genes (topology unchanged): replays skip
     // the tree walk and the descriptor build; transition matrices, CLVs and lnL are recomputed
-    struct ReqSrc { int gene, v, q, fold; };
+    struct ReqSrc { int gene, v, q, fold; };      // branch (v, slot q) whose length a P request uses
     struct Plan {
         bool valid = false; unsigned epoch = 0;
         void *h = nullptr, *d = nullptr; size_t bytes = 0;
@@ -126,9 +128,12 @@ struct Batch {
     // run the collected newviews, then the tail ops (evaluate or sumtable+newton), one sync
     // a tail is evaluated after `after` newview ops of its gene (-1 = after all of them); `slot`
     // selects one of the gene's MAXTAIL sumtable / per-pattern-lnL / result buffers
-    struct Tail { int gene; Side a, b; int mode; double t0; int max_iter; int slot = 0; int after = -1; };
+    struct Tail { int gene; Side a, b; int mode; double t0; int max_iter; int slot = 0; int after = -1;
+                  int bv = -1, bq = 0; /* tree branch (node, slot) t0 comes from: plan replay */ };
     double *res(int g, int slot = 0) const { return h_scalars + 8 * ((size_t)g * MAXTAIL + slot); }
     Side msg(int g, int node, int toward) const;
+    bool is_cherry(int g, int node, int toward) const;
+    bool virtual_cherries = true;      // PML_NO_CHERRY=1 materialises cherry CLVs like any other (A/B switch)
     int run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails);
     int ensure_stage(size_t bytes);
     int ensure_frags(size_t sets);

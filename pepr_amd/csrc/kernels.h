@@ -11,6 +11,8 @@ constexpr int CLV_ROWS = NCAT * NS;    // 80 rows of `mpad` doubles: CLV[cat*20+
 constexpr int PFRAG = NCAT * 25 * 16;      // doubles per transition-matrix fragment set (12.8 KB)
 constexpr int PAT_PER_WAVE = 32;       // one MFMA chunk: 2 N-tiles of 16 patterns (16 B / lane)
 constexpr int NCODES = 23;
+constexpr int TIPTAB_DOUBLES = NCAT * NCODES * NS;   // tip table: T[c][code][s] = sum_{j in code} P_c[s][j]  (14.7 KB)
+constexpr int FRAG_STRIDE = TIPTAB_DOUBLES;          // doubles per k_pmat output slot (fragment set or tip table)
 
 // device-resident model constants (one per ctx)
 struct ModelDev {
@@ -24,27 +26,40 @@ struct ModelDev {
 struct PmatReq {
     double t;
     double rates[NCAT];
-    int fold_pi;            // 1: rows scaled by pi_s (root evaluation)
+    int kind;               // PM_FRAGS, PM_FRAGS_PI (rows scaled by pi_s: root evaluation), PM_TIPTABLE
     int pad;
+};
+enum { PM_FRAGS = 0, PM_FRAGS_PI = 1, PM_TIPTABLE = 2 };
+
+// one side (child) of a CLV operation
+//   SK_CLV    : p0 = CLV (80 x mpad doubles) in HBM
+//   SK_TIP    : p0 = tip codes (uint8[mpad]); t0 = tip table of its branch (newview only)
+//   SK_CHERRY : the child is an inner node whose two other neighbours are tips.  Its CLV is never
+//               materialised: operand[c][s] = T0[c][code0][s] * T1[c][code1][s] from the two tip
+//               tables (p0/p1 = codes of the two tips, t0/t1 = their tables), then contracted with
+//               the fragment set of the branch to the parent like any CLV.
+enum { SK_CLV = 0, SK_TIP = 1, SK_CHERRY = 2 };
+struct OpSide {
+    const void *p0, *p1;
+    const double *t0, *t1;
 };
 
 // one CLV operation (newview / sumtable / evaluate share the descriptor)
 struct NvOp {
     double *out;            // newview: CLV; sumtable: table; evaluate: per-pattern lnL
-    const void *left;       // CLV (double*) or tip codes (uint8*)
-    const void *right;
+    OpSide l, r;
     int *out_scl;           // per-pattern scaling counts of the result (may be null for evaluate)
-    const int *l_scl;       // null for tips
+    const int *l_scl;       // null unless the side is SK_CLV
     const int *r_scl;
-    const double *pl;       // fragment sets (PFRAG doubles)
+    const double *pl;       // fragment sets (PFRAG doubles); null for a newview SK_TIP side
     const double *pr;
     int mpad;               // padded pattern count (multiple of 32)
-    int flags;              // bit0: left is tip, bit1: right is tip
+    int flags;              // bits 0-1: left side kind, bits 2-3: right side kind
     int mode;               // MODE_NEWVIEW / MODE_SUMTABLE / MODE_EVALUATE
     int pad;
     double *aux;            // sumtable ops: the Newton sync block to zero (NEWTON_SYNC_DOUBLES), else null
 };
-static_assert(sizeof(NvOp) == 88, "NvOp layout");
+static_assert(sizeof(NvOp) == 136, "NvOp layout");
 
 // ops [op_begin, op_end) of one gene, in dependency order; executed by every pattern block
 struct GeneRun {

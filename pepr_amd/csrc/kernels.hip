@@ -55,32 +55,48 @@ __device__ __forceinline__ void frag_decode(int idx, int &c, int &row, int &col)
 // k_pmat: P(t r_c) = U diag(exp(lambda t r_c)) U^-1, written directly in MFMA A-fragment order
 // ------------------------------------------------------------------------------------------
 // One block per request.  Thread (row = c*20+s, group g) keeps W[k] = U[s][k] exp(lambda_k r_c t) in
-// registers and produces the outputs j = g, g+3, g+6, ...: one LDS read per FMA instead of three.
+// registers and produces P_c[s][j] for j = g, g+3, g+6, ...: one LDS read per FMA instead of three.
+// PM_FRAGS / PM_FRAGS_PI write MFMA A-fragment order; PM_TIPTABLE writes T[c][code][s] =
+// sum_{j in states(code)} P_c[s][j] (the contraction of a tip's indicator vector, by lookup).
 __global__ __launch_bounds__(256) void k_pmat(const ModelDev *__restrict__ md,
                                               const PmatReq *__restrict__ reqs,
                                               double *__restrict__ frags, int n) {
     __shared__ double e[NCAT * NS];
     __shared__ double sUi[NS * NS];
+    __shared__ double sP[NCAT * NS * NS];      // tip tables only
     const int tid = threadIdx.x;
     const PmatReq req = reqs[blockIdx.x];
     for (int i = tid; i < NS * NS; i += 256) sUi[i] = md->Uinv[i];
     if (tid < NCAT * NS) e[tid] = exp(md->eval[tid % NS] * (req.t * req.rates[tid / NS]));
     __syncthreads();
-    if (tid >= 3 * NCAT * NS) return;
-    const int row = tid % (NCAT * NS), g = tid / (NCAT * NS);
-    const int c = row / NS, s2 = row % NS;
-    double W[NS];
+    double *out = frags + (size_t)blockIdx.x * FRAG_STRIDE;
+    if (tid < 3 * NCAT * NS) {
+        const int row = tid % (NCAT * NS), g = tid / (NCAT * NS);
+        const int c = row / NS, s2 = row % NS;
+        double W[NS];
 #pragma unroll
-    for (int k = 0; k < NS; ++k) W[k] = md->U[s2 * NS + k] * e[c * NS + k];
-    const double scale = req.fold_pi ? md->pi[s2] : 1.0;
-    double *out = frags + (size_t)blockIdx.x * PFRAG;
-    for (int j = g; j < NS; j += 3) {
+        for (int k = 0; k < NS; ++k) W[k] = md->U[s2 * NS + k] * e[c * NS + k];
+        const double scale = req.kind == PM_FRAGS_PI ? md->pi[s2] : 1.0;
+        for (int j = g; j < NS; j += 3) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) v += W[k] * sUi[k * NS + j];
+            if (v < 0.0) v = 0.0;
+            if (req.kind == PM_TIPTABLE) sP[row * NS + j] = v;
+            // fragment element (c, st = s/4, kk = j/4)[4*(j%4) + s%4]
+            else out[((c * 25 + (s2 >> 2) * 5 + (j >> 2)) << 4) + ((j & 3) << 2) + (s2 & 3)] = v * scale;
+        }
+    }
+    if (req.kind != PM_TIPTABLE) return;
+    __syncthreads();
+    for (int idx = tid; idx < TIPTAB_DOUBLES; idx += 256) {
+        const int s2 = idx % NS, code = (idx / NS) % NCODES, c = idx / (NS * NCODES);
+        const unsigned mask = code_mask((unsigned)code);
+        const double *prow = sP + (c * NS + s2) * NS;
         double v = 0.0;
 #pragma unroll
-        for (int k = 0; k < NS; ++k) v += W[k] * sUi[k * NS + j];
-        if (v < 0.0) v = 0.0;
-        // fragment element (c, st = s/4, kk = j/4)[4*(j%4) + s%4]
-        out[((c * 25 + (s2 >> 2) * 5 + (j >> 2)) << 4) + ((j & 3) << 2) + (s2 & 3)] = v * scale;
+        for (int j = 0; j < NS; ++j) if ((mask >> j) & 1u) v += prow[j];
+        out[idx] = v;
     }
 }
 
@@ -148,6 +164,24 @@ __device__ __forceinline__ void contract(double (&acc)[5][2], const double *__re
     }
 }
 
+// cherry operand: product of the two tips' table rows (tables live in global memory, L2-resident:
+// every workgroup of the gene reads the same 2 x 14.7 KB)
+__device__ __forceinline__ void load_cherry(Operand &o, const OpSide &sd, unsigned ca, unsigned cb, int c, int q) {
+    const GLOBAL_AS double *ta = reinterpret_cast<const GLOBAL_AS double *>((gcptr)sd.t0) + (c * NCODES) * NS + q;
+    const GLOBAL_AS double *tb = reinterpret_cast<const GLOBAL_AS double *>((gcptr)sd.t1) + (c * NCODES) * NS + q;
+    const GLOBAL_AS double *a0 = ta + (ca & 0xFFu) * NS, *a1 = ta + (ca >> 8) * NS;
+    const GLOBAL_AS double *b0 = tb + (cb & 0xFFu) * NS, *b1 = tb + (cb >> 8) * NS;
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) o.v[kk] = (dvec2){a0[kk * 4] * b0[kk * 4], a1[kk * 4] * b1[kk * 4]};
+}
+// newview with a tip child: (P . tip)[s] is a table row, no contraction
+__device__ __forceinline__ void lookup_tip(double (&acc)[5][2], const OpSide &sd, unsigned codes, int c, int q) {
+    const GLOBAL_AS double *t = reinterpret_cast<const GLOBAL_AS double *>((gcptr)sd.t0) + (c * NCODES) * NS + q;
+    const GLOBAL_AS double *t0 = t + (codes & 0xFFu) * NS, *t1 = t + (codes >> 8) * NS;
+#pragma unroll
+    for (int st = 0; st < 5; ++st) { acc[st][0] = t0[st * 4]; acc[st][1] = t1[st * 4]; }
+}
+
 // One op on one chunk (32 patterns) of one wave.  All branches on op.* are wave-uniform.
 //   MODE_NEWVIEW : out[c][s] = (P_L,c . L_c)[s] * (P_R,c . R_c)[s], 2^256 rescue, scaling counts
 //   MODE_SUMTABLE: same contraction with the eigen-basis matrices (no rescue), counts = l + r
@@ -158,34 +192,46 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
     const int q = lane >> 4;
     const size_t rowbytes = (size_t)op.mpad * 8;
     const unsigned lane_off = (unsigned)((size_t)q * rowbytes) + (unsigned)p * 8u;
-    const bool ltip = op.flags & 1, rtip = op.flags & 2;
+    const int lk = op.flags & 3, rk = (op.flags >> 2) & 3;
     const int mode = op.mode;
-    gcptr Lp = (gcptr)op.left, Rp = (gcptr)op.right;
+    // a plain tip side goes through the MFMA with its 0/1 indicator operand (the matrix pipe has slack;
+    // table gathers for it measured slower); lookup_tip() is kept for the experiment switch below
+    const bool l_direct = false, r_direct = false;
+    gcptr Lp = (gcptr)op.l.p0, Rp = (gcptr)op.r.p0;
     gptr O = (gptr)op.out;
     // lane's A-fragment element: 4*k + i with k = q, i = lane&3
     const double *fL = sP + (q * 4 + (lane & 3));
     const double *fR = fL + PFRAG;
     double mx0 = 0.0, mx1 = 0.0, site0 = 0.0, site1 = 0.0;
+    unsigned cl = 0, cl2 = 0, cr = 0, cr2 = 0;          // tip codes of the lane's two patterns
+    if (lk != SK_CLV) cl = *reinterpret_cast<const GLOBAL_AS unsigned short *>(Lp + p);
+    if (lk == SK_CHERRY) cl2 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)op.l.p1 + p);
+    if (rk != SK_CLV) cr = *reinterpret_cast<const GLOBAL_AS unsigned short *>(Rp + p);
+    if (rk == SK_CHERRY) cr2 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)op.r.p1 + p);
 
     Operand curL, curR, nxtL, nxtR;
-    if (ltip) load_tip(curL, sT, *reinterpret_cast<const GLOBAL_AS unsigned short *>(Lp + p), q);
-    else load_clv(curL, Lp, lane_off, rowbytes, 0);           // evaluate: left side in output layout
-    if (rtip) load_tip(curR, sT, *reinterpret_cast<const GLOBAL_AS unsigned short *>(Rp + p), q);
-    else load_clv(curR, Rp, lane_off, rowbytes, 0);
+    if (lk == SK_TIP) { if (!l_direct) load_tip(curL, sT, cl, q); }
+    else if (lk == SK_CLV) load_clv(curL, Lp, lane_off, rowbytes, 0);      // evaluate: left side in output layout
+    if (rk == SK_TIP) { if (!r_direct) load_tip(curR, sT, cr, q); }
+    else if (rk == SK_CLV) load_clv(curR, Rp, lane_off, rowbytes, 0);
 #pragma unroll 1
     for (int c = 0; c < NCAT; ++c) {
         if (PREFETCH && c + 1 < NCAT) {                       // software prefetch of the next category
-            if (!ltip) load_clv(nxtL, Lp, lane_off, rowbytes, c + 1);
-            if (!rtip) load_clv(nxtR, Rp, lane_off, rowbytes, c + 1);
+            if (lk == SK_CLV) load_clv(nxtL, Lp, lane_off, rowbytes, c + 1);
+            if (rk == SK_CLV) load_clv(nxtR, Rp, lane_off, rowbytes, c + 1);
         }
+        if (lk == SK_CHERRY) load_cherry(curL, op.l, cl, cl2, c, q);
+        if (rk == SK_CHERRY) load_cherry(curR, op.r, cr, cr2, c, q);
         double aR[5][2];
-        contract(aR, fR + c * 25 * 16, curR);
+        if (r_direct) lookup_tip(aR, op.r, cr, c, q);
+        else contract(aR, fR + c * 25 * 16, curR);
         if (mode == MODE_EVALUATE) {
 #pragma unroll
             for (int st = 0; st < 5; ++st) { site0 += curL.v[st].x * aR[st][0]; site1 += curL.v[st].y * aR[st][1]; }
         } else {
             double aL[5][2];
-            contract(aL, fL + c * 25 * 16, curL);
+            if (l_direct) lookup_tip(aL, op.l, cl, c, q);
+            else contract(aL, fL + c * 25 * 16, curL);
 #pragma unroll
             for (int st = 0; st < 5; ++st) {
                 const double o0 = aL[st][0] * aR[st][0], o1 = aL[st][1] * aR[st][1];
@@ -194,18 +240,18 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
             }
         }
         if (c + 1 < NCAT) {
-            if (PREFETCH) { if (!ltip) curL = nxtL; if (!rtip) curR = nxtR; }
+            if (PREFETCH) { if (lk == SK_CLV) curL = nxtL; if (rk == SK_CLV) curR = nxtR; }
             else {
-                if (!ltip) load_clv(curL, Lp, lane_off, rowbytes, c + 1);
-                if (!rtip) load_clv(curR, Rp, lane_off, rowbytes, c + 1);
+                if (lk == SK_CLV) load_clv(curL, Lp, lane_off, rowbytes, c + 1);
+                if (rk == SK_CLV) load_clv(curR, Rp, lane_off, rowbytes, c + 1);
             }
         }
     }
 
     ivec2 sc = {0, 0};
     if (q == 0) {
-        if (!ltip) sc += *reinterpret_cast<const GLOBAL_AS ivec2 *>((gcptr)op.l_scl + 4 * p);
-        if (!rtip) sc += *reinterpret_cast<const GLOBAL_AS ivec2 *>((gcptr)op.r_scl + 4 * p);
+        if (lk == SK_CLV) sc += *reinterpret_cast<const GLOBAL_AS ivec2 *>((gcptr)op.l_scl + 4 * p);
+        if (rk == SK_CLV) sc += *reinterpret_cast<const GLOBAL_AS ivec2 *>((gcptr)op.r_scl + 4 * p);
     }
     if (mode == MODE_NEWVIEW) {
         mx0 = fmax(mx0, __shfl_xor(mx0, 16)); mx0 = fmax(mx0, __shfl_xor(mx0, 32));
@@ -249,16 +295,17 @@ __device__ __forceinline__ void stage_frags_dma(const NvOp &op, double *dst, int
     // 2*PFRAG doubles = 25 KiB = 25 wave-instructions of 1 KiB (16 B per lane)
     for (int i = wave; i < 25; i += 4) {
         const int e = i * 128 + lane * 2;      // element index of this lane's 16 bytes in [left|right]
-        const double *g = (e < PFRAG) ? op.pl + e : op.pr + (e - PFRAG);
+        const double *g = (e < PFRAG) ? (op.pl ? op.pl : op.pr) + e : (op.pr ? op.pr : op.pl) + (e - PFRAG);
         __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)g, (__attribute__((address_space(3))) void *)(dst + i * 128), 16, 0, 0);
     }
 }
 
 template <int VARIANT>
+// VARIANT 5 = variant 1 compiled for 3 waves/SIMD (168 VGPRs, no spills)
 __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : 3) void k_oplist(
         const NvOp *__restrict__ ops, const GeneRun *__restrict__ runs, int nruns, int blocks_per_gene) {
     constexpr bool PREFETCH = !(VARIANT & 1);
-    constexpr bool DBUF = (VARIANT & 2) != 0;
+    constexpr bool DBUF = (VARIANT & 2) != 0 && VARIANT < 4;
     __shared__ double sP[(DBUF ? 2 : 1) * 2 * PFRAG + TIPTAB / 2];   // 25.6 KB per fragment buffer + tip table
     float *sT = reinterpret_cast<float *>(sP + (DBUF ? 2 : 1) * 2 * PFRAG);
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share
@@ -291,8 +338,8 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : 3) void k_oplist(
             const double2 *gr = reinterpret_cast<const double2 *>(op.pr);
             double2 *s2 = reinterpret_cast<double2 *>(sP);
             for (int i = tid; i < PFRAG / 2; i += 256) {
-                if (op.mode != MODE_EVALUATE) s2[i] = gl[i];
-                s2[PFRAG / 2 + i] = gr[i];
+                if (op.mode != MODE_EVALUATE && op.pl) s2[i] = gl[i];
+                if (op.pr) s2[PFRAG / 2 + i] = gr[i];
             }
             __syncthreads();
         }
@@ -471,7 +518,7 @@ void launch_eigfrags(const ModelDev *model, double *frags2, hipStream_t s) {
 }
 static int oplist_variant() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("PML_OPLIST_VARIANT"); v = e ? atoi(e) & 3 : 1; }
+    if (v < 0) { const char *e = getenv("PML_OPLIST_VARIANT"); v = e ? atoi(e) : 1; }
     return v;
 }
 void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, hipStream_t s) {
@@ -482,6 +529,7 @@ void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad
         case 0: hipLaunchKernelGGL(k_oplist<0>, grid, block, 0, s, ops, runs, nruns, bpg); break;
         case 1: hipLaunchKernelGGL(k_oplist<1>, grid, block, 0, s, ops, runs, nruns, bpg); break;
         case 2: hipLaunchKernelGGL(k_oplist<2>, grid, block, 0, s, ops, runs, nruns, bpg); break;
+        case 5: hipLaunchKernelGGL(k_oplist<5>, grid, block, 0, s, ops, runs, nruns, bpg); break;
         default: hipLaunchKernelGGL(k_oplist<3>, grid, block, 0, s, ops, runs, nruns, bpg); break;
     }
 }
