@@ -90,12 +90,14 @@ __global__ __launch_bounds__(256) void k_pmat(const ModelDev *__restrict__ md,
     if (req.kind != PM_TIPTABLE) return;
     __syncthreads();
     for (int idx = tid; idx < TIPTAB_DOUBLES; idx += 256) {
-        const int s2 = idx % NS, code = (idx / NS) % NCODES, c = idx / (NS * NCODES);
-        const unsigned mask = code_mask((unsigned)code);
-        const double *prow = sP + (c * NS + s2) * NS;
+        const int kk = idx & 7, q = (idx >> 3) & 3, code = (idx >> 5) % NCODES, c = (idx >> 5) / NCODES;
         double v = 0.0;
+        if (kk < 5) {
+            const unsigned mask = code_mask((unsigned)code);
+            const double *prow = sP + (c * NS + 4 * kk + q) * NS;
 #pragma unroll
-        for (int j = 0; j < NS; ++j) if ((mask >> j) & 1u) v += prow[j];
+            for (int j = 0; j < NS; ++j) if ((mask >> j) & 1u) v += prow[j];
+        }
         out[idx] = v;
     }
 }
@@ -164,24 +166,53 @@ __device__ __forceinline__ void contract(double (&acc)[5][2], const double *__re
     }
 }
 
-// cherry operand: product of the two tips' table rows (tables live in global memory, L2-resident:
-// every workgroup of the gene reads the same 2 x 14.7 KB)
-__device__ __forceinline__ void load_cherry(Operand &o, const OpSide &sd, unsigned ca, unsigned cb, int c, int q) {
-    const GLOBAL_AS double *ta = reinterpret_cast<const GLOBAL_AS double *>((gcptr)sd.t0) + (c * NCODES) * NS + q;
-    const GLOBAL_AS double *tb = reinterpret_cast<const GLOBAL_AS double *>((gcptr)sd.t1) + (c * NCODES) * NS + q;
-    const GLOBAL_AS double *a0 = ta + (ca & 0xFFu) * NS, *a1 = ta + (ca >> 8) * NS;
-    const GLOBAL_AS double *b0 = tb + (cb & 0xFFu) * NS, *b1 = tb + (cb >> 8) * NS;
+// st-outer form for the SECOND side: produces one state tile (2 values) at a time so the caller can
+// consume it immediately (multiply with the first side's tile and store): 4 live accumulator
+// registers instead of 40.  Fragments of the next tile are fetched while the current one runs.
+template <typename F>
+__device__ __forceinline__ void contract_stream(const double *__restrict__ frag_c, const Operand &o, F &&consume) {
+    double a_cur[5], a_nxt[5];
 #pragma unroll
-    for (int kk = 0; kk < 5; ++kk) o.v[kk] = (dvec2){a0[kk * 4] * b0[kk * 4], a1[kk * 4] * b1[kk * 4]};
-}
-// newview with a tip child: (P . tip)[s] is a table row, no contraction
-__device__ __forceinline__ void lookup_tip(double (&acc)[5][2], const OpSide &sd, unsigned codes, int c, int q) {
-    const GLOBAL_AS double *t = reinterpret_cast<const GLOBAL_AS double *>((gcptr)sd.t0) + (c * NCODES) * NS + q;
-    const GLOBAL_AS double *t0 = t + (codes & 0xFFu) * NS, *t1 = t + (codes >> 8) * NS;
+    for (int kk = 0; kk < 5; ++kk) a_cur[kk] = frag_c[kk * 16];
 #pragma unroll
-    for (int st = 0; st < 5; ++st) { acc[st][0] = t0[st * 4]; acc[st][1] = t1[st * 4]; }
+    for (int st = 0; st < 5; ++st) {
+        if (st < 4) {
+#pragma unroll
+            for (int kk = 0; kk < 5; ++kk) a_nxt[kk] = frag_c[((st + 1) * 5 + kk) * 16];
+        }
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk) {
+            acc0 = mfma4(a_cur[kk], o.v[kk].x, acc0);
+            acc1 = mfma4(a_cur[kk], o.v[kk].y, acc1);
+        }
+        consume(st, acc0, acc1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk) a_cur[kk] = a_nxt[kk];
+    }
 }
 
+// cherry operand: product of the two tips' table rows (tables live in global memory, L2-resident:
+// every workgroup of the gene reads the same 2 x 23.5 KB); a lane's five rows are 40 contiguous bytes
+struct Rows5 { dvec2 a, b; double c; };
+__device__ __forceinline__ Rows5 load_rows(const double *tab, unsigned code, int c, int q) {
+    gcptr p = (gcptr)tab + ((size_t)((c * NCODES + code) * 4 + q) << 6);
+    Rows5 r;
+    r.a = *reinterpret_cast<const GLOBAL_AS dvec2 *>(p);
+    r.b = *reinterpret_cast<const GLOBAL_AS dvec2 *>(p + 16);
+    r.c = *reinterpret_cast<const GLOBAL_AS double *>(p + 32);
+    return r;
+}
+__device__ __forceinline__ void load_cherry(Operand &o, const OpSide &sd, unsigned ca, unsigned cb, int c, int q) {
+    const Rows5 a0 = load_rows(sd.t0, ca & 0xFFu, c, q), a1 = load_rows(sd.t0, ca >> 8, c, q);
+    const Rows5 b0 = load_rows(sd.t1, cb & 0xFFu, c, q), b1 = load_rows(sd.t1, cb >> 8, c, q);
+    o.v[0] = (dvec2){a0.a.x * b0.a.x, a1.a.x * b1.a.x};
+    o.v[1] = (dvec2){a0.a.y * b0.a.y, a1.a.y * b1.a.y};
+    o.v[2] = (dvec2){a0.b.x * b0.b.x, a1.b.x * b1.b.x};
+    o.v[3] = (dvec2){a0.b.y * b0.b.y, a1.b.y * b1.b.y};
+    o.v[4] = (dvec2){a0.c * b0.c, a1.c * b1.c};
+}
 // One op on one chunk (32 patterns) of one wave.  All branches on op.* are wave-uniform.
 //   MODE_NEWVIEW : out[c][s] = (P_L,c . L_c)[s] * (P_R,c . R_c)[s], 2^256 rescue, scaling counts
 //   MODE_SUMTABLE: same contraction with the eigen-basis matrices (no rescue), counts = l + r
@@ -189,14 +220,15 @@ __device__ __forceinline__ void lookup_tip(double (&acc)[5][2], const OpSide &sd
 template <bool PREFETCH>
 __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restrict__ sP, const float *__restrict__ sT,
                                          int p, int lane) {
+    // `op` refers to the descriptor in global memory (wave-uniform): fields are fetched by scalar loads
+    // where they are used instead of being held in ~34 SGPRs for the whole op
     const int q = lane >> 4;
     const size_t rowbytes = (size_t)op.mpad * 8;
     const unsigned lane_off = (unsigned)((size_t)q * rowbytes) + (unsigned)p * 8u;
     const int lk = op.flags & 3, rk = (op.flags >> 2) & 3;
     const int mode = op.mode;
-    // a plain tip side goes through the MFMA with its 0/1 indicator operand (the matrix pipe has slack;
-    // table gathers for it measured slower); lookup_tip() is kept for the experiment switch below
-    const bool l_direct = false, r_direct = false;
+    // (a plain tip side goes through the MFMA with its 0/1 indicator operand: the matrix pipe has slack and
+    // table gathers for it measured slower)
     gcptr Lp = (gcptr)op.l.p0, Rp = (gcptr)op.r.p0;
     gptr O = (gptr)op.out;
     // lane's A-fragment element: 4*k + i with k = q, i = lane&3
@@ -210,9 +242,9 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
     if (rk == SK_CHERRY) cr2 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)op.r.p1 + p);
 
     Operand curL, curR, nxtL, nxtR;
-    if (lk == SK_TIP) { if (!l_direct) load_tip(curL, sT, cl, q); }
+    if (lk == SK_TIP) load_tip(curL, sT, cl, q);
     else if (lk == SK_CLV) load_clv(curL, Lp, lane_off, rowbytes, 0);      // evaluate: left side in output layout
-    if (rk == SK_TIP) { if (!r_direct) load_tip(curR, sT, cr, q); }
+    if (rk == SK_TIP) load_tip(curR, sT, cr, q);
     else if (rk == SK_CLV) load_clv(curR, Rp, lane_off, rowbytes, 0);
 #pragma unroll 1
     for (int c = 0; c < NCAT; ++c) {
@@ -222,22 +254,18 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
         }
         if (lk == SK_CHERRY) load_cherry(curL, op.l, cl, cl2, c, q);
         if (rk == SK_CHERRY) load_cherry(curR, op.r, cr, cr2, c, q);
-        double aR[5][2];
-        if (r_direct) lookup_tip(aR, op.r, cr, c, q);
-        else contract(aR, fR + c * 25 * 16, curR);
         if (mode == MODE_EVALUATE) {
-#pragma unroll
-            for (int st = 0; st < 5; ++st) { site0 += curL.v[st].x * aR[st][0]; site1 += curL.v[st].y * aR[st][1]; }
+            contract_stream(fR + c * 25 * 16, curR, [&](int st, double y0, double y1) {
+                site0 += curL.v[st].x * y0; site1 += curL.v[st].y * y1;
+            });
         } else {
             double aL[5][2];
-            if (l_direct) lookup_tip(aL, op.l, cl, c, q);
-            else contract(aL, fL + c * 25 * 16, curL);
-#pragma unroll
-            for (int st = 0; st < 5; ++st) {
-                const double o0 = aL[st][0] * aR[st][0], o1 = aL[st][1] * aR[st][1];
+            contract(aL, fL + c * 25 * 16, curL);
+            contract_stream(fR + c * 25 * 16, curR, [&](int st, double y0, double y1) {
+                const double o0 = aL[st][0] * y0, o1 = aL[st][1] * y1;
                 mx0 = fmax(mx0, o0); mx1 = fmax(mx1, o1);
                 *reinterpret_cast<GLOBAL_AS dvec2 *>(O + (size_t)(c * NS + st * 4) * rowbytes + lane_off) = (dvec2){o0, o1};
-            }
+            });
         }
         if (c + 1 < NCAT) {
             if (PREFETCH) { if (lk == SK_CLV) curL = nxtL; if (rk == SK_CLV) curR = nxtR; }
@@ -326,7 +354,7 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : 3) void k_oplist(
     if (DBUF) stage_frags_dma(ops[run.op_begin], sP, lane, wave);
     __syncthreads();
     for (int oi = run.op_begin; oi < run.op_end; ++oi) {
-        const NvOp op = ops[oi];
+        const NvOp &op = ops[oi];
         const double *buf = sP;
         if (DBUF) {
             const int par = (oi - run.op_begin) & 1;
