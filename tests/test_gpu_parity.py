@@ -334,3 +334,28 @@ def test_oneshot_sub_batching(gpu_ctx, monkeypatch):
     sc2 = gpu_ctx.score(G, NW, alpha=0.7, site_lnl=True)
     for a, b in zip(sc, sc2):
         assert a["lnl"] == b["lnl"] and np.array_equal(a["site_lnl"], b["site_lnl"])
+
+
+def test_randomised_shapes_fuzz(gpu_ctx, oracle_lib):
+    """60 random (taxa, sites, missing data, alpha, tree shape) cases in one batch per alpha:
+    per-site lnL against the oracle; covers cherries on both sides, tip-inner, caterpillars,
+    ragged pattern counts around the 32/128 chunk boundaries."""
+    po = oracle_lib
+    rng = np.random.default_rng(2024)
+    for alpha in (0.07, 0.9, 12.0):
+        genes, nws = [], []
+        for i in range(20):
+            nt = int(rng.integers(3, 41)); ns = int(rng.choice([1, 2, 31, 32, 33, 64, 127, 128, 129, 200, 385]))
+            names, rows, nw = synth.simulate_alignment(nt, ns, int(rng.integers(1, 10**6)), missing_frac=float(rng.choice([0.0, 0.2, 0.6])))
+            if i % 5 == 0:          # caterpillar topology on the same taxa
+                order = list(rng.permutation(nt)); nw = names[order[0]]
+                for k in order[1:]:
+                    nw = "(%s:%.4f,%s:%.4f)" % (nw, rng.exponential(0.2), names[k], rng.exponential(0.2))
+                nw += ";"
+            genes.append((names, rows)); nws.append(nw)
+        out = gpu_ctx.score(genes, nws, alpha=alpha, site_lnl=True)
+        for (names, rows), nw, r in zip(genes, nws, out):
+            a = po.Alignment(names, rows); t = po.Tree(nw, a); e = po.Engine(a, po.Model(0), 4, alpha)
+            ref, refs = e.site_lnl(t)
+            assert abs(r["lnl"] - ref) < 1e-9 * max(1.0, abs(ref)), (len(names), len(rows[0]), alpha)
+            assert np.abs(r["site_lnl"] - refs).max() < 1e-9 * max(1.0, np.abs(refs).max())
