@@ -98,6 +98,7 @@ int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *con
                   double alpha, bool score_only) {
     ctx = c; pi_mode = pm; ncat = nc; score_only_batch = score_only;
     virtual_cherries = std::getenv("PML_NO_CHERRY") == nullptr;
+    virtual_pitch = virtual_cherries && std::getenv("PML_NO_PITCH") == nullptr;
     if (n <= 0) return ctx->fail(-1, "empty batch");
     if (nc != 1 && nc != 4) return ctx->fail(-1, "ncat must be 1 or 4");
     if (int rc = ctx->ensure_model(pm)) return rc;
@@ -253,17 +254,28 @@ bool Batch::is_cherry(int g, int node, int toward) const {
     for (int k = 0; k < 3; ++k) { const int w = G.tree.nbr[node][k]; if (w != toward && w >= nt) return false; }
     return true;
 }
+int Batch::virt_kind(int g, int node, int toward) const {
+    if (is_cherry(g, node, toward)) return 1;
+    if (!virtual_pitch) return 0;
+    const Gene &G = genes[g];
+    const int nt = G.aln.ntax;
+    if (node < nt) return 0;
+    int ntip = 0, inner = -1;
+    for (int k = 0; k < 3; ++k) { const int w = G.tree.nbr[node][k]; if (w == toward) continue; if (w < nt) ++ntip; else inner = w; }
+    return (ntip == 1 && inner >= 0 && is_cherry(g, inner, node)) ? 2 : 0;
+}
 Side Batch::msg(int g, int node, int toward) const {
     const Gene &G = genes[g];
     if (node < G.aln.ntax) return {SIDE_TIP, node};
     const int idx = (node - G.aln.ntax) * 3 + G.tree.slot(node, toward);
-    return {is_cherry(g, node, toward) ? SIDE_CHERRY : SIDE_MSG, idx};
+    const int vk = virt_kind(g, node, toward);
+    return {vk == 1 ? SIDE_CHERRY : (vk == 2 ? SIDE_PITCH : SIDE_MSG), idx};
 }
 
 int Batch::need(int g, int v, int to, std::vector<PendingOp> &ops) {
     Gene &G = genes[g];
     const int nt = G.aln.ntax;
-    if (v < nt || is_cherry(g, v, to)) return 0;
+    if (v < nt || virt_kind(g, v, to)) return 0;
     // explicit stack (trees can be caterpillars of depth ~ntax)
     struct Frame { int v, to, k, stage, lv[2]; };
     std::vector<Frame> st;
@@ -282,7 +294,7 @@ int Batch::need(int g, int v, int to, std::vector<PendingOp> &ops) {
         if (f.stage < 2) {
             const int c = ch[f.stage];
             f.stage++;
-            if (c < nt || is_cherry(g, c, f.v)) { ret = 0; continue; }   // tip / virtual cherry child: nothing to compute
+            if (c < nt || virt_kind(g, c, f.v)) { ret = 0; continue; }   // tip / virtual (cherry, pitchfork) child: nothing to compute
             const int fv = f.v;
             st.push_back({c, fv, G.tree.slot(c, fv), 0, {0, 0}});
             continue;
@@ -313,7 +325,8 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     const size_t nops = ops.size(), ntail = tails.size();
     size_t neval = 0, nnewton = 0;
     for (auto &t : tails) { if (t.mode == MODE_EVALUATE) neval++; else nnewton++; }
-    const size_t nreq_max = 6 * nops + 5 * ntail;          // <= 3 requests per side
+    const size_t nreq_max = 10 * nops + 9 * ntail;         // <= 5 requests per side (pitchfork: 3 tables + 2 fragment sets)
+    bool any_pitch = false;
     if (int rc = ensure_frags(std::max(nreq_max, (size_t)1))) return rc;
     if (nnewton > nsync_cap) {
         if (d_nsync) hipFree(d_nsync);
@@ -356,7 +369,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     auto resolve = [&](size_t g, const Side &sd, Resolved &R) -> int {
         Gene &G = genes[g];
         const int mp = G.aln.mpad, nt = G.aln.ntax;
-        R.s = OpSide{nullptr, nullptr, nullptr, nullptr}; R.scl = nullptr;
+        R.s = OpSide{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; R.scl = nullptr;
         if (sd.kind == SIDE_TIP) { R.kind = SK_TIP; R.s.p0 = G.d_codes + (size_t)sd.id * mp; R.bytes = 1; return 0; }
         if (sd.kind == SIDE_CHERRY) {
             const int v = nt + sd.id / 3, k = sd.id % 3;
@@ -367,6 +380,25 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             R.s.t0 = add_req(g, G.tree.len[v][qs[0]], PM_TIPTABLE, v, qs[0]);
             R.s.t1 = add_req(g, G.tree.len[v][qs[1]], PM_TIPTABLE, v, qs[1]);
             R.bytes = 640 + 642;       // SURVEY 8d accounting: the tip-tip newview (642 B) + reading its CLV (640 B)
+            return 0;
+        }
+        if (sd.kind == SIDE_PITCH) {
+            // X over (cherry C = tips a,b ; tip c): tables of a,b,c + the fragments of branch X-C
+            const int X = nt + sd.id / 3, k = sd.id % 3;
+            int qc = -1, qC = -1;
+            for (int q = 0; q < 3; ++q) if (q != k) { if (G.tree.nbr[X][q] < nt) qc = q; else qC = q; }
+            const int C = G.tree.nbr[X][qC], kC = G.tree.slot(C, X);
+            int tips[2], qs[2], ci = 0;
+            for (int q = 0; q < 3; ++q) if (q != kC) { tips[ci] = G.tree.nbr[C][q]; qs[ci] = q; ++ci; }
+            R.kind = SK_PITCH;
+            R.s.p0 = G.d_codes + (size_t)tips[0] * mp; R.s.p1 = G.d_codes + (size_t)tips[1] * mp;
+            R.s.p2 = G.d_codes + (size_t)G.tree.nbr[X][qc] * mp;
+            R.s.t0 = add_req(g, G.tree.len[C][qs[0]], PM_TIPTABLE, C, qs[0]);
+            R.s.t1 = add_req(g, G.tree.len[C][qs[1]], PM_TIPTABLE, C, qs[1]);
+            R.s.t2 = add_req(g, G.tree.len[X][qc], PM_TIPTABLE, X, qc);
+            R.s.f = add_req(g, G.tree.len[X][qC], PM_FRAGS, X, qC);
+            any_pitch = true;
+            R.bytes = 640 + (640 + 642) + 1 + 640;   // read X + X's newview (cherry child, tip child, write)
             return 0;
         }
         const int slot = sd.kind == SIDE_MSG ? G.slot_of[sd.id] : G.slot_cap + sd.id;
@@ -470,7 +502,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     }
     if (nruns) {
         ctx->tic(K_NEWVIEW, algo_bytes);
-        launch_oplist((const NvOp *)(ds + o_ops), (const GeneRun *)(ds + o_runs), (int)nruns, max_mpad, ctx->stream);
+        launch_oplist((const NvOp *)(ds + o_ops), (const GeneRun *)(ds + o_runs), (int)nruns, max_mpad, any_pitch, ctx->stream);
         ctx->toc();
     }
     if (neval) {
@@ -505,7 +537,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         std::memcpy(P.h, hs, bytes);
         HIPCHK(hipMemcpy(P.d, ds, bytes, hipMemcpyDeviceToDevice));
         P.o_req = o_req; P.o_ops = o_ops; P.o_runs = o_runs; P.o_red = o_red;
-        P.nreq = ireq; P.nruns = nruns; P.neval = neval; P.max_mpad = max_mpad; P.algo_bytes = algo_bytes;
+        P.nreq = ireq; P.nruns = nruns; P.neval = neval; P.max_mpad = max_mpad; P.algo_bytes = algo_bytes; P.any_pitch = any_pitch;
         P.src = last_src; P.outs.clear();
         for (auto &o : ops) if (o.out_kind == SIDE_MSG) P.outs.push_back({o.gene, o.out_id});
         P.epoch = topo_epoch; P.valid = true;
@@ -533,7 +565,7 @@ int Batch::replay_plan(double *lnl) {
     launch_pmat(md, (const PmatReq *)(ds + P.o_req), d_frags, (int)P.nreq, ctx->stream);
     ctx->toc();
     ctx->tic(K_NEWVIEW, P.algo_bytes);
-    launch_oplist((const NvOp *)(ds + P.o_ops), (const GeneRun *)(ds + P.o_runs), (int)P.nruns, P.max_mpad, ctx->stream);
+    launch_oplist((const NvOp *)(ds + P.o_ops), (const GeneRun *)(ds + P.o_runs), (int)P.nruns, P.max_mpad, P.any_pitch, ctx->stream);
     ctx->toc();
     ctx->tic(K_REDUCE, 0);
     launch_reduce((const ReduceReq *)(ds + P.o_red), (int)P.neval, ctx->stream);

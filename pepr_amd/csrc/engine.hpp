@@ -66,7 +66,7 @@ struct Gene {
 struct pml_alignment_view { int ntax, nsites; const char *const *names; const char *const *rows; };
 
 constexpr int NSCRATCH = 8;          // extra CLV slots per gene for candidate evaluation (NNI / SPR)
-enum { SIDE_TIP = 0, SIDE_MSG = 1, SIDE_SCRATCH = 2, SIDE_CHERRY = 3 };
+enum { SIDE_TIP = 0, SIDE_MSG = 1, SIDE_SCRATCH = 2, SIDE_CHERRY = 3, SIDE_PITCH = 4 };
 // tip node id | directed-edge index (v-ntax)*3+k | scratch slot | directed-edge index of a message whose
 // two children are tips ("cherry": never materialised, recomputed from two tip tables where consumed)
 struct Side { int kind, id; };
@@ -91,7 +91,7 @@ struct Batch {
         bool valid = false; unsigned epoch = 0;
         void *h = nullptr, *d = nullptr; size_t bytes = 0;
         size_t o_req = 0, o_ops = 0, o_runs = 0, o_red = 0, nreq = 0, nruns = 0, neval = 0;
-        int max_mpad = 0; double algo_bytes = 0;
+        int max_mpad = 0; double algo_bytes = 0; bool any_pitch = false;
         std::vector<ReqSrc> src; std::vector<std::pair<int, int>> outs;
     } plan;
     long cnt_smooth = 0, cnt_nni = 0, cnt_spr = 0, cnt_eval = 0, cnt_passes = 0;   // run() calls by purpose (PML_TRACE)
@@ -133,6 +133,9 @@ struct Batch {
     double *res(int g, int slot = 0) const { return h_scalars + 8 * ((size_t)g * MAXTAIL + slot); }
     Side msg(int g, int node, int toward) const;
     bool is_cherry(int g, int node, int toward) const;
+    // 0: real message, 1: cherry (two tips), 2: pitchfork (a cherry and a tip): both are virtual
+    int virt_kind(int g, int node, int toward) const;
+    bool virtual_pitch = true;         // PML_NO_PITCH=1
     bool virtual_cherries = true;      // PML_NO_CHERRY=1 materialises cherry CLVs like any other (A/B switch)
     int run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails);
     int ensure_stage(size_t bytes);

@@ -40,10 +40,15 @@ enum { PM_FRAGS = 0, PM_FRAGS_PI = 1, PM_TIPTABLE = 2 };
 //               materialised: operand[c][s] = T0[c][code0][s] * T1[c][code1][s] from the two tip
 //               tables (p0/p1 = codes of the two tips, t0/t1 = their tables), then contracted with
 //               the fragment set of the branch to the parent like any CLV.
-enum { SK_CLV = 0, SK_TIP = 1, SK_CHERRY = 2 };
+//   SK_PITCH  : the child X is an inner node over a cherry C (tips a,b) and a tip c ("pitchfork", 3 tips):
+//               CLV_X[c][s] = (P(t_XC) . (T_a * T_b))[s] * T_c[s] is rebuilt in registers (one extra
+//               contraction with the fragment set `f` of branch X-C) and then used like a CLV.
+//               p0,p1,p2 = codes of a,b,c; t0,t1,t2 = their tip tables.
+enum { SK_CLV = 0, SK_TIP = 1, SK_CHERRY = 2, SK_PITCH = 3 };
 struct OpSide {
-    const void *p0, *p1;
-    const double *t0, *t1;
+    const void *p0, *p1, *p2;
+    const double *t0, *t1, *t2;
+    const double *f;
 };
 
 // one CLV operation (newview / sumtable / evaluate share the descriptor)
@@ -61,7 +66,7 @@ struct NvOp {
     int pad;
     double *aux;            // sumtable ops: the Newton sync block to zero (NEWTON_SYNC_DOUBLES), else null
 };
-static_assert(sizeof(NvOp) == 136, "NvOp layout");
+static_assert(sizeof(NvOp) == 184, "NvOp layout");
 
 // ops [op_begin, op_end) of one gene, in dependency order; executed by every pattern block
 struct GeneRun {
@@ -97,7 +102,8 @@ void launch_pmat(const ModelDev *model, const PmatReq *reqs, double *frags, int 
 // constant fragment sets for the eigen-basis transforms used by the sumtable:
 //   set 0: x_i = sum_s pi_s U[s][i] A[s]     set 1: y_i = sum_j Uinv[i][j] B[j]
 void launch_eigfrags(const ModelDev *model, double *frags2, hipStream_t s);
-void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, hipStream_t s);
+// any_pitch: some op has an SK_PITCH side (two more LDS fragment regions are allocated)
+void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, bool any_pitch, hipStream_t s);
 void launch_reduce(const ReduceReq *reqs, int n, hipStream_t s);
 void launch_newton(const ModelDev *model, const NewtonReq *reqs, int n, int max_mpad, hipStream_t s);
 

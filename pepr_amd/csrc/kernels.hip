@@ -136,8 +136,8 @@ __device__ __forceinline__ void load_clv(Operand &o, gcptr base, unsigned lane_o
         o.v[kk] = *reinterpret_cast<const GLOBAL_AS dvec2 *>(base + (size_t)(c * NS + kk * 4) * rowbytes + lane_off);
 }
 // tip operand: 0/1 indicator rows from the LDS table T[code][state] (same for every category)
-__device__ __forceinline__ void load_tip(Operand &o, const float *__restrict__ T, unsigned codes, int q) {
-    const float *t0 = T + (codes & 0xFFu) * NS + q, *t1 = T + (codes >> 8) * NS + q;
+__device__ __forceinline__ void load_tip(Operand &o, const unsigned char *__restrict__ T, unsigned codes, int q) {
+    const unsigned char *t0 = T + (codes & 0xFFu) * NS + q, *t1 = T + (codes >> 8) * NS + q;
 #pragma unroll
     for (int kk = 0; kk < 5; ++kk) o.v[kk] = (dvec2){(double)t0[kk * 4], (double)t1[kk * 4]};
 }
@@ -213,12 +213,27 @@ __device__ __forceinline__ void load_cherry(Operand &o, const OpSide &sd, unsign
     o.v[3] = (dvec2){a0.b.y * b0.b.y, a1.b.y * b1.b.y};
     o.v[4] = (dvec2){a0.c * b0.c, a1.c * b1.c};
 }
+// pitchfork operand for category c: ((F_inner . (T_a * T_b)) * T_c), all in registers
+__device__ __forceinline__ void load_pitch(Operand &o, const OpSide &sd, const double *__restrict__ f_inner,
+                                           unsigned ca, unsigned cb, unsigned cc, int c, int q) {
+    Operand w;
+    load_cherry(w, sd, ca, cb, c, q);
+    double v[5][2];
+    contract(v, f_inner + c * 25 * 16, w);
+    const Rows5 r0 = load_rows(sd.t2, cc & 0xFFu, c, q), r1 = load_rows(sd.t2, cc >> 8, c, q);
+    o.v[0] = (dvec2){v[0][0] * r0.a.x, v[0][1] * r1.a.x};
+    o.v[1] = (dvec2){v[1][0] * r0.a.y, v[1][1] * r1.a.y};
+    o.v[2] = (dvec2){v[2][0] * r0.b.x, v[2][1] * r1.b.x};
+    o.v[3] = (dvec2){v[3][0] * r0.b.y, v[3][1] * r1.b.y};
+    o.v[4] = (dvec2){v[4][0] * r0.c, v[4][1] * r1.c};
+}
+
 // One op on one chunk (32 patterns) of one wave.  All branches on op.* are wave-uniform.
 //   MODE_NEWVIEW : out[c][s] = (P_L,c . L_c)[s] * (P_R,c . R_c)[s], 2^256 rescue, scaling counts
 //   MODE_SUMTABLE: same contraction with the eigen-basis matrices (no rescue), counts = l + r
 //   MODE_EVALUATE: per-pattern ln( 1/4 sum_c sum_s L_c[s] (pi P_c . R_c)[s] ) - counts*256 ln 2
 template <bool PREFETCH>
-__device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restrict__ sP, const float *__restrict__ sT,
+__device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restrict__ sP, const unsigned char *__restrict__ sT,
                                          int p, int lane) {
     // `op` refers to the descriptor in global memory (wave-uniform): fields are fetched by scalar loads
     // where they are used instead of being held in ~34 SGPRs for the whole op
@@ -235,11 +250,17 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
     const double *fL = sP + (q * 4 + (lane & 3));
     const double *fR = fL + PFRAG;
     double mx0 = 0.0, mx1 = 0.0, site0 = 0.0, site1 = 0.0;
-    unsigned cl = 0, cl2 = 0, cr = 0, cr2 = 0;          // tip codes of the lane's two patterns
+    unsigned cl = 0, cl2 = 0, cl3 = 0, cr = 0, cr2 = 0, cr3 = 0;      // tip codes of the lane's two patterns
+    // inner fragments of a pitchfork side: ONE extra LDS region, owned by the left side if it is a
+    // pitchfork, else by the right; if both are, the right side reads its set from global memory (rare)
+    const double *fLi = fL + 2 * PFRAG;
+    const double *fRi = (lk == SK_PITCH) ? op.r.f + (q * 4 + (lane & 3)) : fL + 2 * PFRAG;
     if (lk != SK_CLV) cl = *reinterpret_cast<const GLOBAL_AS unsigned short *>(Lp + p);
-    if (lk == SK_CHERRY) cl2 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)op.l.p1 + p);
+    if (lk >= SK_CHERRY) cl2 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)op.l.p1 + p);
+    if (lk == SK_PITCH) cl3 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)op.l.p2 + p);
     if (rk != SK_CLV) cr = *reinterpret_cast<const GLOBAL_AS unsigned short *>(Rp + p);
-    if (rk == SK_CHERRY) cr2 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)op.r.p1 + p);
+    if (rk >= SK_CHERRY) cr2 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)op.r.p1 + p);
+    if (rk == SK_PITCH) cr3 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)op.r.p2 + p);
 
     Operand curL, curR, nxtL, nxtR;
     if (lk == SK_TIP) load_tip(curL, sT, cl, q);
@@ -253,7 +274,9 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
             if (rk == SK_CLV) load_clv(nxtR, Rp, lane_off, rowbytes, c + 1);
         }
         if (lk == SK_CHERRY) load_cherry(curL, op.l, cl, cl2, c, q);
+        else if (lk == SK_PITCH) load_pitch(curL, op.l, fLi, cl, cl2, cl3, c, q);
         if (rk == SK_CHERRY) load_cherry(curR, op.r, cr, cr2, c, q);
+        else if (rk == SK_PITCH) load_pitch(curR, op.r, fRi, cr, cr2, cr3, c, q);
         if (mode == MODE_EVALUATE) {
             contract_stream(fR + c * 25 * 16, curR, [&](int st, double y0, double y1) {
                 site0 += curL.v[st].x * y0; site1 += curL.v[st].y * y1;
@@ -317,7 +340,7 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
 //         bit1: double-buffered fragment staging by LDS-DMA (one barrier per op)
 // ------------------------------------------------------------------------------------------
 constexpr int PAT_PER_WG = 4 * PAT_PER_WAVE;   // 128
-constexpr int TIPTAB = NCODES * NS;            // 460 floats
+constexpr int TIPTAB = NCODES * NS;            // 460 bytes (0/1 indicators)
 
 __device__ __forceinline__ void stage_frags_dma(const NvOp &op, double *dst, int lane, int wave) {
     // 2*PFRAG doubles = 25 KiB = 25 wave-instructions of 1 KiB (16 B per lane)
@@ -331,11 +354,14 @@ __device__ __forceinline__ void stage_frags_dma(const NvOp &op, double *dst, int
 template <int VARIANT>
 // VARIANT 5 = variant 1 compiled for 3 waves/SIMD (168 VGPRs, no spills)
 __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : 3) void k_oplist(
-        const NvOp *__restrict__ ops, const GeneRun *__restrict__ runs, int nruns, int blocks_per_gene) {
+        const NvOp *__restrict__ ops, const GeneRun *__restrict__ runs, int nruns, int blocks_per_gene, int any_pitch) {
     constexpr bool PREFETCH = !(VARIANT & 1);
     constexpr bool DBUF = (VARIANT & 2) != 0 && VARIANT < 4;
-    __shared__ double sP[(DBUF ? 2 : 1) * 2 * PFRAG + TIPTAB / 2];   // 25.6 KB per fragment buffer + tip table
-    float *sT = reinterpret_cast<float *>(sP + (DBUF ? 2 : 1) * 2 * PFRAG);
+    // dynamic LDS: [left|right] fragments (x2 when double-buffered) [+ left-inner|right-inner fragments of
+    // pitchfork sides when the launch has any] + the float tip-indicator table
+    extern __shared__ double sP[];
+    const int nfrag_regions = (DBUF ? 4 : 2) + (any_pitch ? 1 : 0);
+    unsigned char *sT = reinterpret_cast<unsigned char *>(sP + nfrag_regions * PFRAG);
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share
     // an XCD and its L2), so all pattern blocks of one gene get the same blockIdx % 8: the gene's
     // transition-matrix fragments are then fetched into ONE L2 instead of eight (speed only).
@@ -350,7 +376,7 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : 3) void k_oplist(
     const int p = (blk * 4 + wave) * PAT_PER_WAVE + 2 * (lane & 15);
     const bool active = (blk * 4 + wave) * PAT_PER_WAVE < mpad;
 
-    for (int i = tid; i < TIPTAB; i += 256) sT[i] = (code_mask(i / NS) >> (i % NS)) & 1u ? 1.0f : 0.0f;
+    for (int i = tid; i < TIPTAB; i += 256) sT[i] = (unsigned char)((code_mask(i / NS) >> (i % NS)) & 1u);
     if (DBUF) stage_frags_dma(ops[run.op_begin], sP, lane, wave);
     __syncthreads();
     for (int oi = run.op_begin; oi < run.op_end; ++oi) {
@@ -368,6 +394,14 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : 3) void k_oplist(
             for (int i = tid; i < PFRAG / 2; i += 256) {
                 if (op.mode != MODE_EVALUATE && op.pl) s2[i] = gl[i];
                 if (op.pr) s2[PFRAG / 2 + i] = gr[i];
+            }
+            if (any_pitch) {                 // inner fragment sets of pitchfork sides
+                const int lk = op.flags & 3, rk = (op.flags >> 2) & 3;
+                const double2 *il = reinterpret_cast<const double2 *>(op.l.f), *ir = reinterpret_cast<const double2 *>(op.r.f);
+                for (int i = tid; i < PFRAG / 2; i += 256) {
+                    if (lk == SK_PITCH) s2[PFRAG + i] = il[i];
+                    else if (rk == SK_PITCH) s2[PFRAG + i] = ir[i];
+                }
             }
             __syncthreads();
         }
@@ -549,16 +583,21 @@ static int oplist_variant() {
     if (v < 0) { const char *e = getenv("PML_OPLIST_VARIANT"); v = e ? atoi(e) : 1; }
     return v;
 }
-void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, hipStream_t s) {
+void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, bool any_pitch, hipStream_t s) {
     if (nruns <= 0) return;
     const int bpg = (max_mpad + PAT_PER_WG - 1) / PAT_PER_WG;
     const dim3 grid((unsigned)(((nruns + 7) / 8) * 8 * bpg)), block(256);
-    switch (oplist_variant()) {
-        case 0: hipLaunchKernelGGL(k_oplist<0>, grid, block, 0, s, ops, runs, nruns, bpg); break;
-        case 1: hipLaunchKernelGGL(k_oplist<1>, grid, block, 0, s, ops, runs, nruns, bpg); break;
-        case 2: hipLaunchKernelGGL(k_oplist<2>, grid, block, 0, s, ops, runs, nruns, bpg); break;
-        case 5: hipLaunchKernelGGL(k_oplist<5>, grid, block, 0, s, ops, runs, nruns, bpg); break;
-        default: hipLaunchKernelGGL(k_oplist<3>, grid, block, 0, s, ops, runs, nruns, bpg); break;
+    int v = oplist_variant();
+    if (any_pitch && (v == 2 || v == 3)) v = 1;          // pitchfork regions are not combined with double buffering
+    const bool dbuf = (v == 2 || v == 3);
+    const size_t lds = (size_t)((dbuf ? 4 : 2) + (any_pitch ? 1 : 0)) * PFRAG * sizeof(double) + 512;   // 38.9 KB with pitchforks: 4 per CU
+    const int ap = any_pitch ? 1 : 0;
+    switch (v) {
+        case 0: hipLaunchKernelGGL(k_oplist<0>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
+        case 2: hipLaunchKernelGGL(k_oplist<2>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
+        case 3: hipLaunchKernelGGL(k_oplist<3>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
+        case 5: hipLaunchKernelGGL(k_oplist<5>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
+        default: hipLaunchKernelGGL(k_oplist<1>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
     }
 }
 void launch_reduce(const ReduceReq *reqs, int n, hipStream_t s) {
