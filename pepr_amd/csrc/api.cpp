@@ -6,12 +6,9 @@
 #include <new>
 
 #include "../../include/peprml.h"
-#include "engine.hpp"
+#include "api_types.hpp"
 
 using namespace pml;
-
-struct pml_ctx { Ctx c; };     // (same definition in jackknife.cpp)
-struct pml_batch { Batch b; pml_ctx *owner; };
 
 static thread_local std::string g_err;
 

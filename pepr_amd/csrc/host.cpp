@@ -134,15 +134,17 @@ void gamma_rates(double alpha, int K, double *rates) {
 }
 
 int aa_code(int ch) {
-    static int8_t table[256]; static bool init = false;
-    if (!init) {
-        std::memset(table, 22, sizeof table);
-        const char *aa = "ARNDCQEGHILKMFPSTWYV";
-        for (int i = 0; i < 20; ++i) { table[(unsigned char)aa[i]] = (int8_t)i; table[(unsigned char)std::tolower(aa[i])] = (int8_t)i; }
-        table['B'] = table['b'] = 20; table['Z'] = table['z'] = 21;
-        init = true;
-    }
-    return table[(unsigned char)ch];
+    struct Table {
+        int8_t t[256];
+        Table() {
+            std::memset(t, 22, sizeof t);
+            const char *aa = "ARNDCQEGHILKMFPSTWYV";
+            for (int i = 0; i < 20; ++i) { t[(unsigned char)aa[i]] = (int8_t)i; t[(unsigned char)std::tolower(aa[i])] = (int8_t)i; }
+            t['B'] = t['b'] = 20; t['Z'] = t['z'] = 21;
+        }
+    };
+    static const Table table;          // thread-safe initialisation (genes are encoded on several threads)
+    return table.t[(unsigned char)ch];
 }
 
 bool EncodedAlignment::encode(int nt, int ns, const char *const *nm, const char *const *rows, std::string &err) {

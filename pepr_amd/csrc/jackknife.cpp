@@ -12,11 +12,9 @@
 #include <set>
 
 #include "../../include/peprml.h"
-#include "engine.hpp"
+#include "api_types.hpp"
 
 using namespace pml;
-
-struct pml_ctx { Ctx c; };
 
 namespace {
 struct Concat { std::vector<std::string> names, rows; };
