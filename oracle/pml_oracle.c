@@ -786,7 +786,10 @@ double po_engine_optimize(po_engine *e, po_tree *t, int opt_alpha, double eps) {
     e->ntol = thr * 0.01;
     for (int round = 0; round < 100; round++) {
         mark_all(e);
-        for (int pass = 0; pass < maxpass; pass++) { if (eng_smooth(e, t, thr) < thr) break; }
+        /* geometric pass budget 1, 2, 4, ... maxpass: while alpha is still moving a lot, branch
+         * lengths are not polished to thr (they shift again with the next alpha) */
+        int budget = opt_alpha ? (1 << (round < 5 ? round : 5)) : maxpass; if (budget > maxpass) budget = maxpass;
+        for (int pass = 0; pass < budget; pass++) { if (eng_smooth(e, t, thr) < thr) break; }
         double nl = opt_alpha ? eng_opt_alpha(e, t) : po_engine_lnl(e, t, NULL);
         double gain = nl - lnl; lnl = nl;
         if (gain < eps) break;

@@ -733,7 +733,10 @@ int Batch::optimize(bool opt_alpha_flag, double eps, double *lnl, const std::vec
         if (!any) break;
         std::vector<char> sm(active);
         for (int g = 0; g < n; ++g) if (sm[g]) genes[g].mark_all();
-        for (int pass = 0; pass < maxpass; ++pass) {
+        // geometric pass budget 1, 2, 4, ... maxpass: while alpha is still moving a lot, branch lengths
+        // are not polished to thr (they shift again with the next alpha)
+        const int budget = opt_alpha_flag ? std::min(maxpass, 1 << std::min(round, 5)) : maxpass;
+        for (int pass = 0; pass < budget; ++pass) {
             bool anys = false; for (char a : sm) anys |= a;
             if (!anys) break;
             if (int rc = smooth_pass(sm, md, thr)) return rc;
@@ -748,6 +751,7 @@ int Batch::optimize(bool opt_alpha_flag, double eps, double *lnl, const std::vec
         }
     }
     for (int g = 0; g < n; ++g) if (initial[g]) lnl[g] = cur[g];
+    if (std::getenv("PML_TRACE")) fprintf(stderr, "[pml] optimize(eps %g): cumulative passes %ld smooth-steps %ld evals %ld\n", eps, cnt_passes, cnt_smooth, cnt_eval);
     return 0;
 }
 

@@ -346,6 +346,7 @@ int Batch::search(bool nni, int spr_radius, bool opt_alpha_flag, double eps, dou
             bool anyr = false; for (char a : ract) anyr |= a;
             if (!anyr) break;
             if (int rc = nni_round(ract, lnl, applied)) return rc;
+            if (getenv("PML_TRACE")) { int na = 0, mv = 0; for (int g = 0; g < n; ++g) { na += ract[g]; mv += applied[g]; } fprintf(stderr, "[pml] nni round %d (outer %d): %d genes active, %d moves; cumulative smooth-steps %ld nni-steps %ld\n", round, outer, na, mv, cnt_smooth, cnt_nni); }
             for (int g = 0; g < n; ++g) if (ract[g]) { if (applied[g] == 0) ract[g] = 0; else moves[g] += applied[g]; }
         }
         if (spr_radius > 0) {
