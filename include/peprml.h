@@ -76,6 +76,15 @@ typedef struct {
     int spr_radius;          /* >0: SPR rounds with this rearrangement radius */
     double epsilon;          /* stop when a round gains less than this many lnL units */
     unsigned seed;           /* reserved (search is deterministic) */
+    /* topological constraints, FastTree's -constraints semantics as PEPR produces them
+     * (FastTreeRunner.getFastTreeConstraintsForTree, FastTreeRunner.java:243-273): a 0/1/- matrix,
+     * one row per named taxon, one column per constrained split ('-' = taxon free in that column).
+     * The result tree displays every non-trivial column; taxa absent from the matrix are free.
+     * nconstraints = 0: unconstrained. */
+    int nconstraints;
+    int constraint_ntax;
+    const char *const *constraint_names;
+    const char *const *constraint_rows;
 } pml_search_opts;
 
 typedef struct {

@@ -36,7 +36,9 @@ class Model(C.Structure):
 
 class SearchOpts(C.Structure):
     _fields_ = [("optimize_alpha", C.c_int), ("nni", C.c_int), ("spr_radius", C.c_int),
-                ("epsilon", C.c_double), ("seed", C.c_uint)]
+                ("epsilon", C.c_double), ("seed", C.c_uint),
+                ("nconstraints", C.c_int), ("constraint_ntax", C.c_int),
+                ("constraint_names", C.POINTER(C.c_char_p)), ("constraint_rows", C.POINTER(C.c_char_p))]
 
 
 class JackknifeOpts(C.Structure):

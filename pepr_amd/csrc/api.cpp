@@ -148,7 +148,8 @@ int pml_batch_search(pml_batch *b, const pml_search_opts *opts, double *lnl, dou
     if (!b || !lnl) return PML_EINVAL;
     LOCKED(b);
     int rc;
-    try { rc = b->b.search(opts ? opts->nni != 0 : true, opts ? opts->spr_radius : 0,
+    try { rc = opts ? b->b.set_constraints(opts->nconstraints, opts->constraint_ntax, opts->constraint_names, opts->constraint_rows) : 0;
+          if (!rc) rc = b->b.search(opts ? opts->nni != 0 : true, opts ? opts->spr_radius : 0,
                            opts ? opts->optimize_alpha != 0 : true,
                            (opts && opts->epsilon > 0) ? opts->epsilon : 1e-3, lnl); }
     catch (const std::exception &e) { return b->owner->c.fail(PML_EINVAL, e.what()); }
@@ -184,9 +185,11 @@ static int oneshot_chunk(pml_ctx *ctx, int op, int n, const pml_alignment *alns,
         if (op == OP_SCORE) rc = b->b.score(std::vector<char>(), lnl.data());
         else if (op == OP_OPTIMIZE)
             rc = b->b.optimize(opts ? opts->optimize_alpha != 0 : true, (opts && opts->epsilon > 0) ? opts->epsilon : 1e-4, lnl.data());
-        else
-            rc = b->b.search(opts ? opts->nni != 0 : true, opts ? opts->spr_radius : 0, opts ? opts->optimize_alpha != 0 : true,
-                             (opts && opts->epsilon > 0) ? opts->epsilon : 1e-3, lnl.data());
+        else {
+            rc = opts ? b->b.set_constraints(opts->nconstraints, opts->constraint_ntax, opts->constraint_names, opts->constraint_rows) : 0;
+            if (!rc) rc = b->b.search(opts ? opts->nni != 0 : true, opts ? opts->spr_radius : 0, opts ? opts->optimize_alpha != 0 : true,
+                                      (opts && opts->epsilon > 0) ? opts->epsilon : 1e-3, lnl.data());
+        }
         for (int i = 0; i < n && !rc; ++i) {
             const Gene &G = b->b.genes[i];
             pml_result &r = out[i];

@@ -57,6 +57,7 @@ struct Gene {
     std::vector<int> slot_of;      // directed-edge index (v-ntax)*3+k -> slot (-1 = none)
     std::vector<uint8_t> valid;
     std::vector<int> pend_level;   // scratch for collection (-1 = not pending)
+    std::vector<Constraint> cons;  // topological constraints of the running search (empty = none)
     std::vector<uint8_t> dirty;    // [node*3+slot]: branch needs re-optimisation (both directions set)
     void mark_node(int v) { for (int k = 0; k < 3; ++k) { const int w = tree.nbr[v][k]; if (w < 0) continue; dirty[v * 3 + k] = 1; dirty[w * 3 + tree.slot(w, v)] = 1; } }
     void mark_all() { dirty.assign((size_t)tree.nnodes() * 3, 1); }
@@ -122,6 +123,8 @@ struct Batch {
     int nni_round(const std::vector<char> &active, std::vector<double> &lnl, std::vector<int> &applied);
     int spr_round(const std::vector<char> &active, int radius, std::vector<double> &lnl, std::vector<int> &moves);
     int search(bool nni, int spr_radius, bool opt_alpha_flag, double eps, double *lnl);
+    // FastTree -constraints matrix (names, rows of '0' '1' '-'); start trees that violate it are rebuilt
+    int set_constraints(int ncons, int ntax, const char *const *names, const char *const *rows);
 
     // --- plumbing ---
     int need(int g, int v, int to, std::vector<PendingOp> &ops);   // returns level

@@ -418,7 +418,67 @@ int rf_distance(const Tree &a, const Tree &b) {
 // start tree: neighbour joining on Kimura-corrected protein distances (spec in DESIGN.md
 // "Start tree"; FastTree also starts from NJ -- FastTreeRunner.java:67-94 / SURVEY 3.3)
 // ------------------------------------------------------------------------------------------
-Tree nj_tree(const EncodedAlignment &a) {
+bool split_compatible(const Constraint &c, const std::vector<uint64_t> &X) {
+    bool hit1 = false, hit0 = false, all1 = true, all0 = true;
+    for (size_t i = 0; i < X.size(); ++i) {
+        if (X[i] & c.one[i]) hit1 = true;
+        if (X[i] & c.zero[i]) hit0 = true;
+        if ((X[i] & c.one[i]) != c.one[i]) all1 = false;
+        if ((X[i] & c.zero[i]) != c.zero[i]) all0 = false;
+    }
+    return !hit1 || !hit0 || all1 || all0;
+}
+bool compatible_with_all(const std::vector<Constraint> &cs, const std::vector<uint64_t> &X) {
+    for (const Constraint &c : cs) if (!split_compatible(c, X)) return false;
+    return true;
+}
+std::vector<std::vector<uint64_t>> leaf_sets(const Tree &t) {
+    const int n = t.ntax, words = (n + 63) / 64;
+    std::vector<std::vector<uint64_t>> L((size_t)3 * (n - 2), std::vector<uint64_t>(words, 0));
+    std::vector<uint64_t> all(words, 0);
+    for (int i = 0; i < n; ++i) all[i >> 6] |= 1ULL << (i & 63);
+    // post-order from the inner neighbour of taxon 0: sets of messages pointing towards it, then
+    // every opposite direction is the complement
+    struct F { int v, from, k; };
+    const int r = t.nbr[0][0];
+    std::vector<F> st{{r, -1, 0}};
+    std::vector<int> order;       // (v, from) pairs in pre-order, processed in reverse
+    std::vector<std::pair<int, int>> pre;
+    while (!st.empty()) {
+        F f = st.back(); st.pop_back();
+        pre.push_back({f.v, f.from});
+        if (f.v < n) continue;
+        for (int k = 0; k < 3; ++k) { const int w = t.nbr[f.v][k]; if (w >= 0 && w != f.from) st.push_back({w, f.v, 0}); }
+    }
+    auto down = [&](int v, int from) -> std::vector<uint64_t> & { return L[(v - n) * 3 + t.slot(v, from)]; };
+    for (size_t i = pre.size(); i-- > 0;) {
+        const int v = pre[i].first, from = pre[i].second;
+        if (v < n || from < 0) continue;
+        std::vector<uint64_t> &S = down(v, from);
+        for (int k = 0; k < 3; ++k) {
+            const int w = t.nbr[v][k];
+            if (w == from) continue;
+            if (w < n) S[w >> 6] |= 1ULL << (w & 63);
+            else { const std::vector<uint64_t> &c = down(w, v); for (int q = 0; q < words; ++q) S[q] |= c[q]; }
+        }
+    }
+    // the root node's three messages and all upward messages: complement of the opposite message
+    for (size_t i = 0; i < pre.size(); ++i) {
+        const int v = pre[i].first, from = pre[i].second;
+        if (v < n) { if (from >= n) { std::vector<uint64_t> &U = L[(from - n) * 3 + t.slot(from, v)]; for (int q = 0; q < words; ++q) U[q] = all[q]; U[v >> 6] &= ~(1ULL << (v & 63)); } continue; }
+        if (from < 0) continue;
+        if (from >= n) { std::vector<uint64_t> &U = L[(from - n) * 3 + t.slot(from, v)]; const std::vector<uint64_t> &D = down(v, from); for (int q = 0; q < words; ++q) U[q] = all[q] & ~D[q]; }
+    }
+    return L;
+}
+bool tree_displays(const Tree &t, const std::vector<Constraint> &cs) {
+    if (cs.empty()) return true;
+    const auto L = leaf_sets(t);
+    for (const auto &X : L) if (!compatible_with_all(cs, X)) return false;
+    return true;
+}
+
+Tree nj_tree(const EncodedAlignment &a, const std::vector<Constraint> *cons) {
     const int n = a.ntax, N = 2 * n - 2, mp = a.mpad;
     std::vector<double> D((size_t)N * N, 0.0);
     std::vector<int32_t> w(a.npat);
@@ -446,16 +506,29 @@ Tree nj_tree(const EncodedAlignment &a) {
     std::vector<int> act(n); for (int i = 0; i < n; ++i) act[i] = i;
     int next = n;
     std::vector<double> r(N, 0.0);
+    const bool constrained = cons && !cons->empty();
+    const int words = (n + 63) / 64;
+    std::vector<std::vector<uint64_t>> cl;            // leaf set per node (constrained mode)
+    if (constrained) { cl.assign(N, std::vector<uint64_t>(words, 0)); for (int i = 0; i < n; ++i) cl[i][i >> 6] |= 1ULL << (i & 63); }
     while (act.size() > 3) {
         const int m = (int)act.size();
         for (int x : act) { double s = 0; for (int y : act) s += D[(size_t)x * N + y]; r[x] = s; }
-        double best = 1e300; int bi = 0, bj = 1;
+        double best = 1e300; int bi = -1, bj = -1;
+        std::vector<uint64_t> X(words);
+        for (int pass = 0; pass < 2 && bi < 0; ++pass)   // pass 1 (only if no compatible pair exists): unconstrained
         for (int ai = 0; ai < m; ++ai) for (int bjx = ai + 1; bjx < m; ++bjx) {
             const int x = act[ai], y = act[bjx];
             const double q = (m - 2) * D[(size_t)x * N + y] - r[x] - r[y];
-            if (q < best) { best = q; bi = ai; bj = bjx; }
+            if (q < best) {
+                if (constrained && pass == 0) {
+                    for (int w = 0; w < words; ++w) X[w] = cl[x][w] | cl[y][w];
+                    if (!compatible_with_all(*cons, X)) continue;
+                }
+                best = q; bi = ai; bj = bjx;
+            }
         }
         const int x = act[bi], y = act[bj], u = next++;
+        if (constrained) for (int w = 0; w < words; ++w) cl[u][w] = cl[x][w] | cl[y][w];
         const double dxy = D[(size_t)x * N + y];
         const double lx = 0.5 * dxy + (r[x] - r[y]) / (2.0 * (m - 2));
         connect(u, x, lx); connect(u, y, dxy - lx);

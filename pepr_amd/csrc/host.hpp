@@ -58,7 +58,17 @@ struct EncodedAlignment {
     bool encode(int ntax, int nsites, const char *const *names, const char *const *rows, std::string &err);
 };
 
-Tree nj_tree(const EncodedAlignment &a);
+// a constrained split over the gene's taxa: side '1' and side '0' as bitsets ('-' taxa in neither)
+struct Constraint { std::vector<uint64_t> one, zero; };
+// X (bitset of a cluster / clade) is compatible with the split: misses one side or contains one side
+bool split_compatible(const Constraint &c, const std::vector<uint64_t> &X);
+bool compatible_with_all(const std::vector<Constraint> &cs, const std::vector<uint64_t> &X);
+// leaf sets of all directed messages: L[(v-ntax)*3+k] = taxa on v's side of edge (v, nbr[v][k])
+std::vector<std::vector<uint64_t>> leaf_sets(const Tree &t);
+bool tree_displays(const Tree &t, const std::vector<Constraint> &cs);
+
+// NJ start tree; with constraints only joins whose cluster is compatible with every split are made
+Tree nj_tree(const EncodedAlignment &a, const std::vector<Constraint> *cons = nullptr);
 
 // resumable Brent minimiser on a fixed interval (same control flow as the oracle's eng_opt_alpha)
 struct Brent {

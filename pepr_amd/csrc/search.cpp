@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 
 #include "engine.hpp"
@@ -43,6 +44,31 @@ void nni_apply(Tree &T, int u, int v, int alt, double tnew) {
     T.set_len(u, v, tnew);
 }
 }  // namespace
+
+// FastTree -constraints semantics (FastTreeRunner.java:54-64, 243-273): every 0/1 column is a split
+// the result must display; taxa the matrix does not name, or marks '-', are free in that column
+int Batch::set_constraints(int ncons, int ntax, const char *const *names, const char *const *rows) {
+    for (Gene &G : genes) G.cons.clear();
+    if (ncons <= 0 || ntax <= 0) return 0;
+    if (!names || !rows) return ctx->fail(-1, "constraint matrix missing");
+    for (int i = 0; i < ntax; ++i) if (!names[i] || !rows[i] || (int)strnlen(rows[i], (size_t)ncons) < ncons) return ctx->fail(-1, "constraint row shorter than nconstraints");
+    for (Gene &G : genes) {
+        const int n = G.aln.ntax, words = (n + 63) / 64;
+        std::vector<int> map(ntax, -1);
+        for (int i = 0; i < ntax; ++i) for (int t = 0; t < n; ++t) if (G.aln.names[t] == names[i]) { map[i] = t; break; }
+        for (int c = 0; c < ncons; ++c) {
+            Constraint K; K.one.assign(words, 0); K.zero.assign(words, 0);
+            int n1 = 0, n0 = 0;
+            for (int i = 0; i < ntax; ++i) {
+                const int t = map[i]; if (t < 0) continue;
+                if (rows[i][c] == '1') { K.one[t >> 6] |= 1ULL << (t & 63); ++n1; }
+                else if (rows[i][c] == '0') { K.zero[t >> 6] |= 1ULL << (t & 63); ++n0; }
+            }
+            if (n1 >= 2 && n0 >= 2) G.cons.push_back(K);        // smaller sides are trivially displayed
+        }
+    }
+    return 0;
+}
 
 // <= 2 smoothing passes (stop when max |dt| < 1e-3), then lnL
 int Batch::light_smooth(const std::vector<char> &active, double *lnl) {
@@ -107,8 +133,27 @@ int Batch::nni_round(const std::vector<char> &active, std::vector<double> &lnl, 
     std::vector<char> stageA(n, 0);
     for (int g = 0; g < n; ++g) {
         if (!active[g]) continue;
+        std::vector<std::vector<uint64_t>> leafs;
+        if (!genes[g].cons.empty()) leafs = leaf_sets(genes[g].tree);
         for (size_t e = 0; e < edges[g].size(); ++e) {
-            const double Lc = L[g][3 * e], L1 = L[g][3 * e + 1], L2 = L[g][3 * e + 2];
+            const double Lc = L[g][3 * e];
+            double L1 = L[g][3 * e + 1], L2 = L[g][3 * e + 2];
+            if (!genes[g].cons.empty()) {          // an alternative whose new split violates a constraint is not a candidate
+                const Tree &T = genes[g].tree; const int nt = T.ntax;
+                const int u = edges[g][e].first, v = edges[g][e].second;
+                int a[2], c[2]; double la[2], lc[2];
+                others(T, u, v, a, la); others(T, v, u, c, lc);
+                auto setof = [&](int node, int toward) {
+                    std::vector<uint64_t> S((nt + 63) / 64, 0);
+                    if (node < nt) S[node >> 6] |= 1ULL << (node & 63); else S = leafs[(node - nt) * 3 + T.slot(node, toward)];
+                    return S;
+                };
+                for (int alt = 1; alt <= 2; ++alt) {
+                    std::vector<uint64_t> X = setof(a[0], u); const std::vector<uint64_t> Y = setof(c[alt - 1], v);
+                    for (size_t w = 0; w < X.size(); ++w) X[w] |= Y[w];
+                    if (!compatible_with_all(genes[g].cons, X)) (alt == 1 ? L1 : L2) = -1e300;
+                }
+            }
             const int best = (L2 > L1) ? 2 : 1;
             const double gain = (best == 1 ? L1 : L2) - Lc;
             if (gain > NNI_MIN_GAIN) cands[g].push_back({edges[g][e].first, edges[g][e].second, best, gain, Tn[g][3 * e + best], (int)cands[g].size()});
@@ -200,7 +245,24 @@ int Batch::spr_round(const std::vector<char> &active, int radius, std::vector<do
         S.x = xy[0]; S.y = xy[1]; S.tx = lxy[0]; S.ty = lxy[1]; S.ts = T.len[S.p][S.ks];
         S.units.clear(); S.ui = 0; S.best = -1e300; S.bg = S.bh = -1; S.phase = 0;
         std::vector<PathOp> pending;
+        // constraints: regrafting beyond edge (gg,h) turns its split into L(h side) + L(S); if that is
+        // incompatible, neither this edge nor anything behind it is a candidate
+        const std::vector<Constraint> &cons = genes[g].cons;
+        std::vector<std::vector<uint64_t>> leafs; std::vector<uint64_t> LS;
+        if (!cons.empty()) {
+            leafs = leaf_sets(T);
+            LS.assign((nt + 63) / 64, 0);
+            if (S.s < nt) LS[S.s >> 6] |= 1ULL << (S.s & 63); else LS = leafs[(S.s - nt) * 3 + T.slot(S.s, S.p)];
+        }
+        auto allowed = [&](int gg, int h) {
+            if (cons.empty()) return true;
+            std::vector<uint64_t> X((nt + 63) / 64, 0);
+            if (h < nt) X[h >> 6] |= 1ULL << (h & 63); else X = leafs[(h - nt) * 3 + T.slot(h, gg)];
+            for (size_t w = 0; w < X.size(); ++w) X[w] |= LS[w];
+            return compatible_with_all(cons, X);
+        };
         std::function<void(int, int, int)> explore = [&](int gg, int h, int depth) {
+            if (!allowed(gg, h)) { pending.clear(); return; }
             Unit u; u.paths = pending; pending.clear(); u.g = gg; u.h = h; u.mslot = depth - 1;
             S.units.push_back(u);
             if (h < nt || depth >= radius) return;
@@ -333,6 +395,10 @@ int Batch::spr_round(const std::vector<char> &active, int radius, std::vector<do
 int Batch::search(bool nni, int spr_radius, bool opt_alpha_flag, double eps, double *lnl_out) {
     const int n = (int)genes.size();
     std::vector<double> lnl(n, 0.0);
+    for (int g = 0; g < n; ++g) {         // a start tree that violates the constraints is replaced by a constrained NJ tree
+        Gene &G = genes[g];
+        if (!G.cons.empty() && !tree_displays(G.tree, G.cons)) { G.tree = nj_tree(G.aln, &G.cons); invalidate_all(g); ++topo_epoch; }
+    }
     newton_tol = 1e-6;                    // candidate ranking and local moves: coarse Newton
     struct Restore { double &r; ~Restore() { r = 1e-8; } } restore{newton_tol};
     if (int rc = optimize(opt_alpha_flag, 0.1, lnl.data())) return rc;
@@ -367,6 +433,7 @@ int Batch::search(bool nni, int spr_radius, bool opt_alpha_flag, double eps, dou
     if (int rc = optimize(opt_alpha_flag, eps, lnl.data())) return rc;
     if (getenv("PML_TRACE")) fprintf(stderr, "[pml] search done: passes %ld smooth-steps %ld nni-steps %ld spr-steps %ld evals %ld\n", cnt_passes, cnt_smooth, cnt_nni, cnt_spr, cnt_eval);
     for (int g = 0; g < n; ++g) lnl_out[g] = lnl[g];
+    for (int g = 0; g < n; ++g) if (!tree_displays(genes[g].tree, genes[g].cons)) return ctx->fail(-5, "internal: result violates the topological constraints");
     return 0;
 }
 

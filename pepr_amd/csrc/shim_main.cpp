@@ -3,7 +3,7 @@
 // (.../util/ExecUtilities.java:168-190; .../pipeline/PhyloPipeline.java:846-870).
 // Built twice: -DSHIM_FASTTREE -> bin/FastTree_WAG, -DSHIM_RAXML -> bin/raxmlHPC (+ -PTHREADS).
 // Accepts exactly the argv subsets PEPR emits:
-//   FastTree_WAG -gamma [-nosupport] <aln.faa>                      FastTreeRunner.java:67-86
+//   FastTree_WAG -gamma [-nosupport] [-constraints <c.faa>] <aln.faa>   FastTreeRunner.java:67-86
 //   raxmlHPC -f d|e|g -m PROTGAMMAWAG -s <aln.phy> -n <run> [-t tree] [-z trees] [-T n] [-p seed]
 //                                                                   RAxMLRunner.java:115-132,196-208,253-272
 // Everything numeric happens in libpeprml.so (HIP); these files only parse and print.
@@ -76,13 +76,13 @@ static int fail(const char *tool, const std::string &msg) { std::fprintf(stderr,
 #ifdef SHIM_FASTTREE
 int main(int argc, char **argv) {
     const char *tool = "FastTree_WAG";
-    const char *file = nullptr; bool gamma = false;
+    const char *file = nullptr, *cons_file = nullptr; bool gamma = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "-gamma") gamma = true;
         else if (a == "-nosupport" || a == "-quiet" || a == "-nopr") {}
         else if (a == "-gtr" || a == "-nt") return fail(tool, "nucleotide models are not built (PEPR never requests them)");
-        else if (a == "-constraints") return fail(tool, "-constraints is not built yet (SURVEY 8f-4)");
+        else if (a == "-constraints" && i + 1 < argc) cons_file = argv[++i];
         else if (a == "-log" && i + 1 < argc) ++i;
         else if (a[0] == '-') return fail(tool, "unknown option " + a);
         else file = argv[i];
@@ -96,6 +96,14 @@ int main(int argc, char **argv) {
     std::vector<const char *> np, rp; pml_alignment v = view(a, np, rp);
     pml_model model = {4, 1.0, PML_PI_RAXML_3DP};
     pml_search_opts opts = {1, 1, 0, 1e-3, 0};         // NJ start + NNI rounds, as FastTree's ML stage
+    Aln cons; std::vector<const char *> cnp, crp;
+    if (cons_file) {                                   // FastTreeRunner.java:54-64: FASTA of 0/1/- rows
+        if (!read_fasta(cons_file, cons, err)) return fail(tool, "constraints: " + err);
+        for (auto &x : cons.names) cnp.push_back(x.c_str());
+        for (auto &x : cons.rows) crp.push_back(x.c_str());
+        opts.nconstraints = (int)cons.rows[0].size(); opts.constraint_ntax = (int)cons.names.size();
+        opts.constraint_names = cnp.data(); opts.constraint_rows = crp.data();
+    }
     pml_result res;
     const int rc = pml_search(ctx, &v, nullptr, &model, &opts, &res);
     if (rc) { std::string m = pml_last_error(ctx); pml_destroy(ctx); return fail(tool, m); }

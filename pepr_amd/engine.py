@@ -38,8 +38,56 @@ def _model(ncat=4, alpha=1.0, pi_mode=PI_RAXML_3DP):
     return _lib.Model(ncat, alpha, pi_mode)
 
 
-def _opts(optimize_alpha=True, nni=True, spr_radius=0, epsilon=0.0, seed=0):
-    return _lib.SearchOpts(int(optimize_alpha), int(nni), int(spr_radius), float(epsilon), int(seed))
+def _opts(optimize_alpha=True, nni=True, spr_radius=0, epsilon=0.0, seed=0, constraints=None, keep=None):
+    """constraints: (names, rows) -- FastTree-style 0/1/- matrix, one row per named taxon."""
+    o = _lib.SearchOpts(int(optimize_alpha), int(nni), int(spr_radius), float(epsilon), int(seed), 0, 0, None, None)
+    if constraints is not None:
+        names, rows = constraints
+        n = len(names)
+        na = (C.c_char_p * n)(*[s.encode() for s in names])
+        ra = (C.c_char_p * n)(*[s.encode() for s in rows])
+        if keep is not None:
+            keep.extend([na, ra])
+        o.nconstraints = len(rows[0]) if n else 0
+        o.constraint_ntax = n
+        o.constraint_names = na
+        o.constraint_rows = ra
+        o._keep = (na, ra)
+    return o
+
+
+def constraints_from_tree(newick):
+    """The 0/1 matrix FastTreeRunner.getFastTreeConstraintsForTree builds (FastTreeRunner.java:243-273):
+    taxa sorted by name, one column per node of the constraint tree (1 = leaf below that node)."""
+    import re
+    s = newick.strip().rstrip(";")
+    pos = 0
+    cols = []
+
+    def node():
+        nonlocal pos
+        leaves = []
+        if s[pos] == "(":
+            pos += 1
+            while True:
+                leaves += node()
+                if s[pos] == ",":
+                    pos += 1
+                    continue
+                if s[pos] == ")":
+                    pos += 1
+                    break
+            m = re.match(r"[^,():;]*(:[-+0-9.eE]+)?", s[pos:])
+            pos += len(m.group(0))
+        else:
+            m = re.match(r"([^,():;]*)(:[-+0-9.eE]+)?", s[pos:])
+            pos += len(m.group(0))
+            leaves = [m.group(1)]
+        cols.append(set(leaves))
+        return leaves
+    taxa = sorted(node())
+    rows = ["".join("1" if t in c else "0" for c in cols) for t in taxa]
+    return taxa, rows
 
 
 class Context:
@@ -100,8 +148,8 @@ class Context:
         return self._oneshot(self.L.pml_optimize_batch, genes, newicks, _model(ncat, alpha, pi_mode), (C.byref(o),))
 
     def search(self, genes, start_newicks=None, alpha=1.0, ncat=4, pi_mode=PI_RAXML_3DP, optimize_alpha=True,
-               nni=True, spr_radius=0, epsilon=1e-3):
-        o = _opts(optimize_alpha, nni, spr_radius, epsilon)
+               nni=True, spr_radius=0, epsilon=1e-3, constraints=None):
+        o = _opts(optimize_alpha, nni, spr_radius, epsilon, constraints=constraints)
         return self._oneshot(self.L.pml_search_batch, genes, start_newicks, _model(ncat, alpha, pi_mode), (C.byref(o),))
 
     def jackknife(self, genes, reps=100, subset_size=0, seed=0, spr_radius_full=5, epsilon=1e-3, alpha=1.0,
@@ -192,8 +240,8 @@ class Batch:
         self.ctx._check(self.L.pml_batch_optimize(self.ptr, C.byref(o), lnl.ctypes.data_as(dp), al.ctypes.data_as(dp)))
         return lnl, al
 
-    def search(self, optimize_alpha=True, nni=True, spr_radius=0, epsilon=1e-3):
-        o = _opts(optimize_alpha, nni, spr_radius, epsilon)
+    def search(self, optimize_alpha=True, nni=True, spr_radius=0, epsilon=1e-3, constraints=None):
+        o = _opts(optimize_alpha, nni, spr_radius, epsilon, constraints=constraints)
         lnl, al = np.zeros(self.n), np.zeros(self.n)
         dp = C.POINTER(C.c_double)
         self.ctx._check(self.L.pml_batch_search(self.ptr, C.byref(o), lnl.ctypes.data_as(dp), al.ctypes.data_as(dp)))

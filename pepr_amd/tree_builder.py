@@ -12,7 +12,7 @@ Behaviour kept from the reference: a failed build leaves the result `None` (Fast
 125-131 logs and continues; callers see a null tree string); the ML matrix is a RAxML model
 string (default PROTGAMMAWAG, PhylogenomicPipeline2.java:248-250); threads/processes are accepted
 and ignored (the GPU engine needs no -T).  Not mirrored (out of scope): parsimony
-(-y), rapid bootstrap (-f a), nucleotide (-gtr -nt), constraints.
+(-y), rapid bootstrap (-f a), nucleotide (-gtr -nt).
 """
 import logging
 
@@ -127,12 +127,35 @@ class FastTreeRunner:
         self.useRaxmlBranchLengths = False
         self.bootstrapReps = 0
         self.lnl = None
+        self.constraints = None
 
     def setAlignment(self, a):
         self.alignment = a
 
     def getAlignment(self):
         return self.alignment
+
+    def setConstraints(self, fasta_text):
+        """FASTA text of 0/1/- rows, one column per constrained split (FastTreeRunner.java:220-222)."""
+        self.constraints = fasta_text
+
+    def setConstraintTree(self, treeString):
+        """One column per node of the tree: 1 = leaf below the node (FastTreeRunner.java:224-229,243-273)."""
+        if treeString is not None:
+            names, rows = engine.constraints_from_tree(treeString)
+            self.setConstraints("".join(">%s\n%s\n" % (n, r) for n, r in zip(names, rows)))
+
+    def _constraint_matrix(self):
+        if self.constraints is None:
+            return None
+        names, rows = [], []
+        for line in self.constraints.splitlines():
+            line = line.strip()
+            if line.startswith(">"):
+                names.append(line[1:]); rows.append("")
+            elif line and names:
+                rows[-1] += line
+        return names, rows
 
     def setUseRaxmlBranchLengths(self, b):
         self.useRaxmlBranchLengths = b
@@ -157,7 +180,8 @@ class FastTreeRunner:
         """`FastTree_WAG -gamma -nosupport`: NJ start + NNI hill climbing under WAG+Gamma."""
         ctx = self.ctx or default_context()
         try:
-            r = ctx.search([self.alignment.as_gene()], None, nni=True, spr_radius=0, pi_mode=engine.PI_RAXML_3DP)[0]
+            r = ctx.search([self.alignment.as_gene()], None, nni=True, spr_radius=0, pi_mode=engine.PI_RAXML_3DP,
+                           constraints=self._constraint_matrix())[0]
             self.result, self.lnl = r["newick"], r["lnl"]
         except Exception as e:
             log.error("FastTreeRunner failed: %s", e)
@@ -233,6 +257,8 @@ class PhylogeneticTreeBuilder:
             f = FastTreeRunner(self.ctx)
             f.setAlignment(self.alignment); f.setRunName(self.runName); f.setBootstrapReps(self.bootstrapReps)
             f.setUseRaxmlBranchLengths(self._useRaxmlBL)
+            if self.constraintTree is not None:             # PhylogeneticTreeBuilder.java:190-192
+                f.setConstraintTree(self.constraintTree)
             f.run()
             self.setTreeString(f.getResult())
         else:

@@ -27,7 +27,7 @@ def test_header_symbols_exported():
 
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.Alignment) == 24 and C.sizeof(_lib.Model) == 24
-    assert C.sizeof(_lib.Result) == 56 and C.sizeof(_lib.SearchOpts) == 32
+    assert C.sizeof(_lib.Result) == 56 and C.sizeof(_lib.SearchOpts) == 56
 
 
 def test_strerror_and_version():

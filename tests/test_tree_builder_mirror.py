@@ -40,3 +40,29 @@ def test_builder_runs_both_methods(gpu_ctx):
     # per-site lnL mode (RAxMLRunner.runRaxmlPerSiteLL :162-213)
     r = tb.RAxMLRunner(1, gpu_ctx); r.setAlignment(aln); r.setPerSiteLogLikelihoods(True); r.setPerSiteLLTrees([nw]); r.run()
     assert len(r.getPerSiteLLs()) == 1 and len(r.getPerSiteLLs()[0]) == 300
+
+
+def test_constraint_tree_text_cpu():
+    """setConstraintTree builds the FASTA text FastTreeRunner.java:243-273 writes to <aln>.con:
+    taxa sorted, one 0/1 column per node of the tree, in the order nodes close."""
+    f = tb.FastTreeRunner()
+    f.setConstraintTree("((b:1,a:1):1,(c:1,(e:1,d:1):1):1);")
+    names, rows = f._constraint_matrix()
+    assert names == ["a", "b", "c", "d", "e"] and all(len(r) == 9 for r in rows)
+    cols = ["".join(r[j] for r in rows) for j in range(9)]
+    assert sorted(cols) == sorted(["01000", "10000", "11000", "00100", "00001", "00010", "00011", "00111", "11111"])
+    assert f.constraints.startswith(">a\n")
+    f2 = tb.FastTreeRunner(); f2.setConstraintTree(None)
+    assert f2._constraint_matrix() is None
+
+
+@pytest.mark.gpu
+def test_builder_constraint_tree(gpu_ctx):
+    import util
+    names, rows, nw = synth.simulate_alignment(10, 200, 93)
+    b = tb.PhylogeneticTreeBuilder(gpu_ctx)
+    b.setAlignment(tb.SequenceAlignment(names, rows)); b.setTreeBuildingMethod(tb.FAST_TREE)
+    b.setConstraintTree("((t1,t5,t8),(t0,t2,t3,t4,t6,t7,t9));")      # one multifurcating clade, rest free
+    b.run()
+    sp = util.splits(b.getTreeString())
+    assert frozenset(["t1", "t5", "t8"]) in sp or frozenset(names) - frozenset(["t1", "t5", "t8"]) in sp
