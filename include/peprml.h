@@ -17,6 +17,9 @@
  *   pml_jackknife  <- .../pepr/tree/pipeline/PhylogenomicPipeline2.java:994-1126
  *                        buildConcatenatedTreeWithGeneWiseJackKnifeSupport(): full tree + N support trees on
  *                        random gene subsets (:959-977, 1227-1275, 1587-1633) + support counts, ONE call
+ *   pml_parsimony  <- .../pepr/tree/RAxMLRunner.java:215-251  runRaxmlParsimonyWithBranchLengths():
+ *                        `raxmlHPC -f d -y` -> RAxML_parsimonyTree.<run> (topology only); the caller then
+ *                        runs pml_optimize on it, as the reference runs `-f e -t` (:253-272)
  *   pml_concatenate<- .../pepr/alignment/MSAConcatenator.java:78-189 (sorted taxon union, '?' padding)
  *   pml_support_tree<- .../pepr/tree/TreeSupportDecorator.java:86-163 addSupportValues(): integer
  *                        bipartition counts of the support trees written as node labels of the main tree
@@ -165,6 +168,13 @@ typedef struct {
 int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *genes, const pml_model *model,
                   const pml_jackknife_opts *opts, pml_result *main_out /* newick carries the supports */,
                   char **support_newicks_out /* optional: reps lines, '\n'-separated; pml_free */);
+/* Maximum-parsimony trees (Fitch lengths on the device): randomised stepwise addition (seed 0 =
+ * input order) then SPR hill climbing within spr_radius edges (0 = none; RAxML uses 20).  out[i].newick is
+ * topology only; out[i].lnl / alpha / tree_length are 0; mp_length[i] (optional) = weighted Fitch length. */
+typedef struct { unsigned seed; int spr_radius; } pml_parsimony_opts;
+int pml_parsimony(pml_ctx *ctx, const pml_alignment *aln, const pml_parsimony_opts *opts, pml_result *out, long long *mp_length);
+int pml_parsimony_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const pml_parsimony_opts *opts,
+                        pml_result *out, long long *mp_length);
 /* host-only: FASTA text (">taxon\nSEQ\n" per taxon, SequenceAlignment.java:405-416) of the
  * concatenation of the selected genes (sel == NULL: all), taxa = sorted union, '?' padding */
 int pml_concatenate(int ngenes, const pml_alignment *genes, int nsel, const int *sel, char **fasta_out);

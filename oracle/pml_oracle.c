@@ -1112,3 +1112,158 @@ double po_engine_search(po_engine *e, po_tree **t_inout, int spr_radius, double 
     e->dirty = (unsigned char *)calloc((size_t)e->nnodes * 3, 1); e->dirty_next = (unsigned char *)calloc((size_t)e->nnodes * 3, 1);
     return po_engine_optimize(e, t, 1, eps);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Maximum-parsimony start tree (`raxmlHPC -f d -y`, reference call site RAxMLRunner.java:215-251;
+ * the program's source is not in the reference).  Restates the published procedure: Fitch (1971)
+ * state sets, randomised stepwise addition (each taxon goes to the edge with the smallest length
+ * increase), then subtree-pruning-regrafting hill climbing within `radius` edges.  Integer
+ * arithmetic only, so the HIP path must agree bit for bit.  PARITY UNPINNED against RAxML 7.2.5
+ * (its random addition order cannot be reproduced without running it); pinned against an
+ * independent Fitch length in tests/util.py and brute-force minimum length on tiny cases.
+ *
+ * Shared spec (engine: pepr_amd/csrc/parsimony.hip):
+ *   F(l,r) = (l&r) ? (l&r) : (l|r);   S(tip) = po_code_mask(code);   S(v->u) = F of v's other two inputs
+ *   order: identity if seed==0 else Fisher-Yates (i = n-1..1, j = splitmix64() % (i+1))
+ *   start: inner node ntax joined to order[0..2]; step t adds tip order[t] with new inner node ntax+t-2
+ *   edge enumeration: v ascending over present nodes, slot k ascending, neighbour u > v
+ *   cost(e, X) = sum_p w_p [F(S(v->u), S(u->v)) & X == 0]; first minimum wins
+ *   SPR round: prunes enumerated (v inner ascending, k ascending: subtree behind nbr[v][k]),
+ *   a = nbr[v][(k+1)%3], b = nbr[v][(k+2)%3]; candidates by DFS from a (carrying S(b->v)) then from
+ *   b (carrying S(a->v)), children in slot order, depth <= radius; gain = cost(orig) - cost(cand);
+ *   the largest gain > 0 (first in enumeration on ties) is applied; repeat until none.
+ * ------------------------------------------------------------------------------------------ */
+static unsigned long long sm64(unsigned long long *s) {
+    unsigned long long z = (*s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+typedef struct {
+    const po_aln *a; po_tree *t; int np;
+    unsigned *tip;          /* [ntax][np] */
+    unsigned *msg;          /* [(v-ntax)*3+k][np] = S(v -> nbr[v][k]) */
+    unsigned char *ok;
+} pars_ctx;
+static unsigned fitch(unsigned l, unsigned r) { unsigned x = l & r; return x ? x : (l | r); }
+static const unsigned *pars_msg(pars_ctx *c, int v, int to) {
+    const po_tree *t = c->t;
+    if (v < t->ntax) return c->tip + (size_t)v * c->np;
+    int k = slot_of(t, v, to), i = (v - t->ntax) * 3 + k;
+    unsigned *out = c->msg + (size_t)i * c->np;
+    if (!c->ok[i]) {
+        const unsigned *l = pars_msg(c, t->nbr[v][(k + 1) % 3], v), *r = pars_msg(c, t->nbr[v][(k + 2) % 3], v);
+        for (int p = 0; p < c->np; p++) out[p] = fitch(l[p], r[p]);
+        c->ok[i] = 1;
+    }
+    return out;
+}
+static long long pars_cost3(const pars_ctx *c, const unsigned *l, const unsigned *r, const unsigned *x) {
+    long long s = 0;
+    for (int p = 0; p < c->np; p++) if (!(fitch(l[p], r[p]) & x[p])) s += c->a->weight[p];
+    return s;
+}
+static void pars_reset(pars_ctx *c) { memset(c->ok, 0, (size_t)(c->t->nnodes - c->t->ntax) * 3); }
+static long long pars_len_rec(pars_ctx *c, int v, int from) {      /* changes below v seen from `from` */
+    const po_tree *t = c->t;
+    if (v < t->ntax) return 0;
+    int k = slot_of(t, v, from), x = t->nbr[v][(k + 1) % 3], y = t->nbr[v][(k + 2) % 3];
+    long long s = pars_len_rec(c, x, v) + pars_len_rec(c, y, v);
+    const unsigned *l = pars_msg(c, x, v), *r = pars_msg(c, y, v);
+    for (int p = 0; p < c->np; p++) if (!(l[p] & r[p])) s += c->a->weight[p];
+    return s;
+}
+static long long pars_length(pars_ctx *c, int root_tip) {
+    int r = c->t->nbr[root_tip][0];
+    long long s = pars_len_rec(c, r, root_tip);
+    const unsigned *l = pars_msg(c, r, root_tip), *x = c->tip + (size_t)root_tip * c->np;
+    for (int p = 0; p < c->np; p++) if (!(l[p] & x[p])) s += c->a->weight[p];
+    return s;
+}
+long long po_parsimony_length(const po_aln *a, const po_tree *t) {
+    pars_ctx c; c.a = a; c.t = (po_tree *)t; c.np = a->npat;
+    c.tip = (unsigned *)malloc(sizeof(unsigned) * (size_t)a->ntax * a->npat);
+    c.msg = (unsigned *)malloc(sizeof(unsigned) * (size_t)(t->nnodes - t->ntax) * 3 * a->npat);
+    c.ok = (unsigned char *)calloc((size_t)(t->nnodes - t->ntax) * 3, 1);
+    for (int i = 0; i < a->ntax; i++) for (int p = 0; p < a->npat; p++) c.tip[(size_t)i * a->npat + p] = po_code_mask(a->codes[(size_t)i * a->npat + p]);
+    long long L = pars_length(&c, 0);
+    free(c.tip); free(c.msg); free(c.ok);
+    return L;
+}
+typedef struct { pars_ctx *c; const unsigned *P; int radius; long long base, best_gain; int bv, bk, bg, bh; int v, k; unsigned *path; } pspr;
+static void pspr_explore(pspr *s, const unsigned *M0, int g, int from, int depth) {
+    /* M0 = message arriving at g from the pruned side (tree without the subtree) */
+    pars_ctx *c = s->c; const po_tree *t = c->t;
+    if (g < t->ntax) return;
+    int kf = slot_of(t, g, from);
+    for (int j = 1; j <= 2; j++) {
+        int h = t->nbr[g][(kf + j) % 3], o = t->nbr[g][(kf + 3 - j) % 3];
+        unsigned *M1 = s->path + (size_t)depth * c->np;
+        const unsigned *so = pars_msg(c, o, g);
+        for (int p = 0; p < c->np; p++) M1[p] = fitch(M0[p], so[p]);
+        long long cost = pars_cost3(c, M1, pars_msg(c, h, g), s->P);
+        long long gain = s->base - cost;
+        if (gain > s->best_gain) { s->best_gain = gain; s->bv = s->v; s->bk = s->k; s->bg = g; s->bh = h; }
+        if (depth < s->radius) pspr_explore(s, M1, h, g, depth + 1);
+    }
+}
+static void pars_spr_apply(po_tree *t, int v, int k, int g, int h) {
+    int a = t->nbr[v][(k + 1) % 3], b = t->nbr[v][(k + 2) % 3];
+    t->nbr[a][slot_of(t, a, v)] = b; t->nbr[b][slot_of(t, b, v)] = a;
+    t->nbr[g][slot_of(t, g, h)] = v; t->nbr[h][slot_of(t, h, g)] = v;
+    t->nbr[v][(k + 1) % 3] = g; t->nbr[v][(k + 2) % 3] = h;
+}
+po_tree *po_parsimony_tree(const po_aln *a, unsigned seed, int radius, long long *length_out, int *moves_out) {
+    int n = a->ntax, np = a->npat;
+    po_tree *t = t_alloc(n);
+    for (int i = 0; i < t->nnodes; i++) for (int k = 0; k < 3; k++) t->len[i][k] = 0.1;
+    pars_ctx c; c.a = a; c.t = t; c.np = np;
+    c.tip = (unsigned *)malloc(sizeof(unsigned) * (size_t)n * np);
+    c.msg = (unsigned *)malloc(sizeof(unsigned) * (size_t)(n - 2) * 3 * np);
+    c.ok = (unsigned char *)calloc((size_t)(n - 2) * 3, 1);
+    for (int i = 0; i < n; i++) for (int p = 0; p < np; p++) c.tip[(size_t)i * np + p] = po_code_mask(a->codes[(size_t)i * np + p]);
+    int *order = (int *)malloc(sizeof(int) * n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    if (seed) { unsigned long long st = seed; for (int i = n - 1; i >= 1; i--) { int j = (int)(sm64(&st) % (unsigned long long)(i + 1)); int x = order[i]; order[i] = order[j]; order[j] = x; } }
+    for (int k = 0; k < 3; k++) { t->nbr[n][k] = order[k]; t->nbr[order[k]][0] = n; }
+    for (int s = 3; s < n; s++) {
+        int x = order[s], w = n + s - 2;
+        const unsigned *X = c.tip + (size_t)x * np;
+        pars_reset(&c);
+        long long best = -1; int bv = -1, bu = -1;
+        for (int v = 0; v < t->nnodes; v++) {
+            if (t->nbr[v][0] < 0) continue;
+            for (int k = 0; k < 3; k++) {
+                int u = t->nbr[v][k];
+                if (u < 0 || u < v) continue;
+                long long cost = pars_cost3(&c, pars_msg(&c, v, u), pars_msg(&c, u, v), X);
+                if (best < 0 || cost < best) { best = cost; bv = v; bu = u; }
+            }
+        }
+        t->nbr[bv][slot_of(t, bv, bu)] = w; t->nbr[bu][slot_of(t, bu, bv)] = w;
+        t->nbr[w][0] = bv; t->nbr[w][1] = bu; t->nbr[w][2] = x; t->nbr[x][0] = w;
+    }
+    int moves = 0;
+    if (radius > 0 && n > 4) {
+        pspr s; s.c = &c; s.radius = radius; s.path = (unsigned *)malloc(sizeof(unsigned) * (size_t)(radius + 2) * np);
+        for (int round = 0; round < 20 * n; round++) {
+            pars_reset(&c);
+            s.best_gain = 0;
+            for (int v = n; v < t->nnodes; v++) for (int k = 0; k < 3; k++) {
+                int sub = t->nbr[v][k], x = t->nbr[v][(k + 1) % 3], y = t->nbr[v][(k + 2) % 3];
+                if (x < n && y < n) continue;
+                s.P = pars_msg(&c, sub, v); s.v = v; s.k = k;
+                s.base = pars_cost3(&c, pars_msg(&c, x, v), pars_msg(&c, y, v), s.P);
+                pspr_explore(&s, pars_msg(&c, y, v), x, v, 1);
+                pspr_explore(&s, pars_msg(&c, x, v), y, v, 1);
+            }
+            if (s.best_gain <= 0) break;
+            pars_spr_apply(t, s.bv, s.bk, s.bg, s.bh); moves++;
+        }
+        free(s.path);
+    }
+    pars_reset(&c);
+    if (length_out) *length_out = pars_length(&c, 0);
+    if (moves_out) *moves_out = moves;
+    free(order); free(c.tip); free(c.msg); free(c.ok);
+    return t;
+}

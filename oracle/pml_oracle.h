@@ -102,6 +102,10 @@ void po_engine_branch_derivs(po_engine *e, const po_tree *t, int u, int v, doubl
 double po_engine_search(po_engine *e, po_tree **t_inout, int spr_radius, double eps);
 po_tree *po_nj_tree(const po_aln *a);
 
+/* ---- parsimony (`raxmlHPC -y` start tree; spec in pml_oracle.c) ---- */
+long long po_parsimony_length(const po_aln *a, const po_tree *t);     /* weighted Fitch length */
+po_tree *po_parsimony_tree(const po_aln *a, unsigned seed, int radius, long long *length_out, int *moves_out);
+
 /* brute force (tiny trees only): sums over all inner-state assignments; independent of pruning */
 double po_bruteforce_lnl(const po_aln *a, const po_model *m, int ncat, double alpha,
                          const po_tree *t);

@@ -63,6 +63,10 @@ def lib():
         L.po_engine_search.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_double]
         L.po_nj_tree.restype = vp
         L.po_nj_tree.argtypes = [vp]
+        L.po_parsimony_length.restype = C.c_longlong
+        L.po_parsimony_length.argtypes = [vp, vp]
+        L.po_parsimony_tree.restype = vp
+        L.po_parsimony_tree.argtypes = [vp, C.c_uint, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]
         L.free = C.CDLL(None).free
         L.free.argtypes = [vp]
         _LIB = L
@@ -211,3 +215,14 @@ def nj_tree(aln):
 
 def bruteforce_lnl(aln, model, tree, ncat=4, alpha=1.0):
     return lib().po_bruteforce_lnl(aln.ptr, model.ptr, ncat, alpha, tree.ptr)
+
+
+def parsimony_length(aln, tree):
+    return lib().po_parsimony_length(aln.ptr, tree.ptr)
+
+
+def parsimony_tree(aln, seed=0, radius=20):
+    """-> (Tree, weighted Fitch length, number of SPR moves applied)"""
+    ln, mv = C.c_longlong(), C.c_int()
+    p = lib().po_parsimony_tree(aln.ptr, seed, radius, C.byref(ln), C.byref(mv))
+    return Tree(aln=aln, ptr=p), ln.value, mv.value

@@ -288,6 +288,30 @@ int pml_support_tree(const char *main_newick, int ntrees, const char *const *sup
     return *out ? PML_OK : PML_ENOMEM;
 }
 
+int pml_parsimony_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const pml_parsimony_opts *opts, pml_result *out, long long *mp_length) {
+    if (!ctx || !alns || !out || n <= 0) return PML_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->c.mu);
+    for (int i = 0; i < n; ++i) std::memset(&out[i], 0, sizeof(pml_result));
+    try {
+        if (hipSetDevice(ctx->c.device) != hipSuccess) return ctx->c.fail(PML_EDEVICE, "hipSetDevice failed");
+        std::vector<Tree> trees; std::vector<EncodedAlignment> enc; std::vector<long long> len; std::vector<int> moves;
+        const int rc = parsimony_batch(&ctx->c, n, reinterpret_cast<const pml_alignment_view *>(alns), opts ? opts->seed : 0u,
+                                       opts ? opts->spr_radius : 20, trees, enc, len, moves);
+        if (rc) { for (int i = 0; i < n; ++i) out[i].status = rc; return rc; }
+        for (int i = 0; i < n; ++i) {
+            out[i].npatterns = enc[i].npat; out[i].nsites = enc[i].nsites;
+            out[i].newick = dup_string(trees[i].newick(enc[i].names, -1));
+            if (!out[i].newick) return ctx->c.fail(PML_ENOMEM, "host allocation failed");
+            if (mp_length) mp_length[i] = len[i];
+        }
+    } catch (const std::bad_alloc &) { return ctx->c.fail(PML_ENOMEM, "host allocation failed"); }
+    catch (const std::exception &e) { return ctx->c.fail(PML_EINVAL, e.what()); }
+    return PML_OK;
+}
+int pml_parsimony(pml_ctx *ctx, const pml_alignment *aln, const pml_parsimony_opts *opts, pml_result *out, long long *mp_length) {
+    return pml_parsimony_batch(ctx, 1, aln, opts, out, mp_length);
+}
+
 int pml_kernel_stats(pml_ctx *ctx, int k, long long *launches, double *ms, double *bytes) {
     if (!ctx || k < 0 || k >= K_COUNT) return PML_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->c.mu);

@@ -146,4 +146,8 @@ struct Batch {
     int slot_for(Gene &g, int idx);
 };
 
+// parsimony.hip: Fitch parsimony trees (stepwise addition + SPR) for n genes, one launch per device step
+int parsimony_batch(Ctx *ctx, int n, const pml_alignment_view *alns, unsigned seed, int radius, std::vector<Tree> &trees_out,
+                    std::vector<EncodedAlignment> &alns_out, std::vector<long long> &lengths_out, std::vector<int> &moves_out);
+
 }  // namespace pml

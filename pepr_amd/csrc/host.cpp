@@ -331,10 +331,10 @@ std::string Tree::newick(const std::vector<std::string> &names, int digits) cons
             for (int k = 0; k < 3; ++k) { const int w = nbr[v][k]; if (w < 0 || w == from) continue; if (!first) out += ','; first = false; rec(w, v, len[v][k]); }
             out += ')';
         }
-        std::snprintf(buf, sizeof buf, ":%.*f", digits, l); out += buf;
+        if (digits >= 0) { std::snprintf(buf, sizeof buf, ":%.*f", digits, l); out += buf; }     // digits < 0: topology only
     };
     const int r = nbr[0][0];
-    out += '('; out += names[0]; std::snprintf(buf, sizeof buf, ":%.*f", digits, len[0][0]); out += buf;
+    out += '('; out += names[0]; if (digits >= 0) { std::snprintf(buf, sizeof buf, ":%.*f", digits, len[0][0]); out += buf; }
     for (int k = 0; k < 3; ++k) { const int w = nbr[r][k]; if (w < 0 || w == 0) continue; out += ','; rec(w, r, len[r][k]); }
     out += ");";
     return out;

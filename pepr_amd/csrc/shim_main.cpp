@@ -119,6 +119,7 @@ int main(int argc, char **argv) {
 int main(int argc, char **argv) {
     const char *tool = "raxmlHPC";
     std::string f = "d", model_s = "PROTGAMMAWAG", aln_f, run, tree_f, trees_f;
+    bool pars_only = false; unsigned seed = 12345;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto val = [&](std::string &dst) { if (i + 1 >= argc) return false; dst = argv[++i]; return true; };
@@ -129,8 +130,10 @@ int main(int argc, char **argv) {
         else if (a == "-n") { if (!val(run)) return fail(tool, "-n needs a value"); }
         else if (a == "-t") { if (!val(tree_f)) return fail(tool, "-t needs a value"); }
         else if (a == "-z") { if (!val(trees_f)) return fail(tool, "-z needs a value"); }
-        else if (a == "-T" || a == "-p") { if (!val(dummy)) return fail(tool, a + " needs a value"); }
-        else if (a == "-y" || a == "-Y") return fail(tool, "parsimony-only mode (-y) is not built (SURVEY 8a-5)");
+        else if (a == "-T") { if (!val(dummy)) return fail(tool, a + " needs a value"); }
+        else if (a == "-p") { if (!val(dummy)) return fail(tool, a + " needs a value"); seed = (unsigned)std::strtoul(dummy.c_str(), nullptr, 10); }
+        else if (a == "-y") pars_only = true;              // RAxMLRunner.java:134-140,241-251: parsimony start tree only
+        else if (a == "-Y") return fail(tool, "parsimony bootstrap (-Y -N) is not built");
         else if (a == "-x" || a == "-N") return fail(tool, "rapid bootstrap (-f a -x -N) is not built; PEPR's jackknife uses reps=0");
         else return fail(tool, "unknown option " + a);
     }
@@ -146,7 +149,16 @@ int main(int argc, char **argv) {
     std::ofstream info("RAxML_info." + run), logf("RAxML_log." + run);
     info << "peprml raxmlHPC shim (MI355X HIP engine), model " << model_s << ", alignment " << aln_f << "\n";
     int rc = 0;
-    if (f == "d") {
+    if (f == "d" && pars_only) {
+        pml_parsimony_opts po = {seed, 20};
+        pml_result res; long long mp = 0;
+        rc = pml_parsimony(ctx, &v, &po, &res, &mp);
+        if (!rc) {
+            std::ofstream("RAxML_parsimonyTree." + run) << res.newick << "\n";     // topology only, read at RAxMLRunner.java:338-359
+            info << "Parsimony tree length: " << mp << "\n";
+            pml_result_free(&res);
+        }
+    } else if (f == "d") {
         pml_search_opts opts = {1, 1, 5, 1e-3, 0};          // NNI + lazy SPR radius 5 ("best rearrangement setting 5")
         pml_result res;
         rc = pml_search(ctx, &v, nullptr, &model, &opts, &res);

@@ -152,6 +152,24 @@ class Context:
         o = _opts(optimize_alpha, nni, spr_radius, epsilon, constraints=constraints)
         return self._oneshot(self.L.pml_search_batch, genes, start_newicks, _model(ncat, alpha, pi_mode), (C.byref(o),))
 
+    def parsimony(self, genes, seed=0, spr_radius=20):
+        """`raxmlHPC -y` start trees (RAxMLRunner.java:215-251): list of {"newick" (topology only), "length"}."""
+        keep = []
+        n = len(genes)
+        alns = (_lib.Alignment * n)(*[_aln_struct(g[0], g[1], keep) for g in genes])
+        o = _lib.ParsimonyOpts(int(seed), int(spr_radius))
+        res = (_lib.Result * n)()
+        mp = (C.c_longlong * n)()
+        rc = self.L.pml_parsimony_batch(self.ptr, n, alns, C.byref(o), res, mp)
+        out = []
+        if rc == 0:
+            out = [{"newick": C.string_at(r.newick).decode(), "length": int(mp[i]), "npatterns": r.npatterns}
+                   for i, r in enumerate(res)]
+        for r in res:
+            self.L.pml_result_free(C.byref(r))
+        self._check(rc)
+        return out
+
     def jackknife(self, genes, reps=100, subset_size=0, seed=0, spr_radius_full=5, epsilon=1e-3, alpha=1.0,
                   ncat=4, pi_mode=PI_RAXML_3DP):
         """Full tree + `reps` gene-subset support trees + support counts (PhylogenomicPipeline2.java:994-1126).

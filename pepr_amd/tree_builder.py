@@ -11,8 +11,8 @@ read like the reference's own call sites; every `run()` goes through the C ABI
 Behaviour kept from the reference: a failed build leaves the result `None` (FastTreeRunner.java:
 125-131 logs and continues; callers see a null tree string); the ML matrix is a RAxML model
 string (default PROTGAMMAWAG, PhylogenomicPipeline2.java:248-250); threads/processes are accepted
-and ignored (the GPU engine needs no -T).  Not mirrored (out of scope): parsimony
-(-y), rapid bootstrap (-f a), nucleotide (-gtr -nt).
+and ignored (the GPU engine needs no -T).  Not mirrored (out of scope): rapid
+bootstrap (-f a), parsimony bootstrap (-Y), nucleotide (-gtr -nt).
 """
 import logging
 
@@ -69,6 +69,10 @@ class RAxMLRunner:
         self.lnl = None
         self.alpha = None
         self.spr_radius = 5           # RAxML "best rearrangement setting 5" 
+        self.algorithm = 0            # 1 = parsimony only, 2 = parsimony + ML lengths (RAxMLRunner.java:28-29)
+        self.parsimonyTree = None
+        self.parsimonyWithBLTree = None
+        self.seed = 12345
 
     def setAlignment(self, a):
         self.alignment = a
@@ -84,6 +88,20 @@ class RAxMLRunner:
 
     def setUseTaxonNames(self, b):
         pass
+
+    def setParsimonyOnly(self, b):          # RAxMLRunner.java:542-548
+        if b:
+            self.algorithm = 1
+
+    def setParsimonyWithBL(self, b):        # RAxMLRunner.java:550-556
+        if b:
+            self.algorithm = 2
+
+    def getParsimonyTree(self):             # RAxML_parsimonyTree.<run>, RAxMLRunner.java:338-359
+        return self.parsimonyTree
+
+    def getParsimonyWithBLTree(self):       # RAxML_result.<run>BL, RAxMLRunner.java:361-383
+        return self.parsimonyWithBLTree
 
     def setPerSiteLogLikelihoods(self, b):
         self.perSiteLL = b
@@ -104,13 +122,22 @@ class RAxMLRunner:
                     r = ctx.score([gene], [o["newick"]], alpha=o["alpha"], site_lnl=True, **mdl)[0]
                     self.perSiteLLs.append(r["site_lnl"])
                 return
+            if self.algorithm in (1, 2):
+                if self.bootstrapReps:
+                    raise ValueError("parsimony bootstrap (-Y -N) is not on the GPU path")
+                p = ctx.parsimony([gene], seed=self.seed)[0]                  # -f d -y
+                self.parsimonyTree = p["newick"]
+                if self.algorithm == 2:                                        # -f e -t RAxML_parsimonyTree.<run>
+                    o = ctx.optimize([gene], [p["newick"]], **mdl)[0]
+                    self.parsimonyWithBLTree, self.lnl, self.alpha = o["newick"], o["lnl"], o["alpha"]
+                return
             if self.bootstrapReps:
                 raise ValueError("rapid bootstrap (-f a) is not on the GPU path; PEPR's jackknife uses reps=0")
             r = ctx.search([gene], None, spr_radius=self.spr_radius, **mdl)[0]
             self.bestTree, self.lnl, self.alpha = r["newick"], r["lnl"], r["alpha"]
         except Exception as e:          # reference: rc logged, result stays null
             log.error("RAxMLRunner failed: %s", e)
-            self.bestTree = None
+            self.bestTree = self.parsimonyTree = self.parsimonyWithBLTree = None
 
     def getBestTree(self):
         return self.bestTree
@@ -253,6 +280,15 @@ class PhylogeneticTreeBuilder:
             r.setBootstrapReps(self.bootstrapReps); r.setAlignment(self.alignment); r.setMatrix(self.mlMatrix)
             r.run()
             self.setTreeString(r.getBestTree())
+        elif self.treeBuildingMethod in (PARSIMONY, PARSIMONY_BL):        # PhylogeneticTreeBuilder.java:136-161
+            r = RAxMLRunner(self.processes, self.ctx)
+            if self.treeBuildingMethod == PARSIMONY:
+                r.setParsimonyOnly(True)
+            else:
+                r.setParsimonyWithBL(True)
+            r.setBootstrapReps(self.bootstrapReps); r.setAlignment(self.alignment)
+            r.run()
+            self.setTreeString(r.getParsimonyTree() if self.treeBuildingMethod == PARSIMONY else r.getParsimonyWithBLTree())
         elif self.treeBuildingMethod == FAST_TREE:
             f = FastTreeRunner(self.ctx)
             f.setAlignment(self.alignment); f.setRunName(self.runName); f.setBootstrapReps(self.bootstrapReps)
@@ -262,4 +298,4 @@ class PhylogeneticTreeBuilder:
             f.run()
             self.setTreeString(f.getResult())
         else:
-            raise ValueError("tree building method %r is outside the GPU path (ml, FastTree)" % self.treeBuildingMethod)
+            raise ValueError("tree building method %r is outside the GPU path (ml, FastTree, parsimony, parsimony_bl)" % self.treeBuildingMethod)

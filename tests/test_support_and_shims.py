@@ -37,8 +37,8 @@ def test_shims_exist_and_reject_bad_usage(tmp_path):
     assert r.returncode != 0 and "cannot open" in r.stderr and r.stdout == ""
     r = run([FT, "-gtr", "-nt", "x.faa"])
     assert r.returncode != 0 and "nucleotide" in r.stderr
-    r = run([RX, "-f", "d", "-m", "PROTGAMMAWAG", "-s", "x.phy", "-n", "r1", "-y"])
-    assert r.returncode != 0 and "parsimony" in r.stderr
+    r = run([RX, "-f", "d", "-m", "PROTGAMMAWAG", "-s", "x.phy", "-n", "r1", "-Y", "-N", "10"])
+    assert r.returncode != 0 and "parsimony bootstrap" in r.stderr
     r = run([RX, "-f", "d", "-m", "GTRGAMMA", "-s", "x.phy", "-n", "r1"])
     assert r.returncode != 0 and "WAG" in r.stderr
     (tmp_path / "RAxML_info.r2").write_text("old run\n")          # RAxML refuses a used run name (RAxMLRunner.java:518-532)

@@ -9,7 +9,7 @@ from pepr_amd import synth, tree_builder as tb
 def test_dispatch_and_errors_cpu():
     b = tb.PhylogeneticTreeBuilder()
     b.setAlignment(tb.SequenceAlignment(["a", "b", "c"], ["AR", "AR", "AQ"]))
-    b.setTreeBuildingMethod(tb.PARSIMONY)
+    b.setTreeBuildingMethod(tb.NEIGHBOR_JOINING)
     with pytest.raises(ValueError):
         b.run()                                   # outside the GPU path, said loudly
     with pytest.raises(ValueError):

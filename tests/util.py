@@ -118,3 +118,34 @@ def rf_collapsed(nw_a, nw_b, min_len=1e-5):
     a, b = splits(nw_a), splits(nw_b)
     d = sum(1 for s, l in a.items() if l > min_len and s not in b) + sum(1 for s, l in b.items() if l > min_len and s not in a)
     return d
+
+
+def fitch_length(names, rows, newick):
+    """Independent Fitch (1971) length in numpy over raw columns (no pattern compression):
+    gap/?/X = any state, B = N|D, Z = Q|E.  The unrooted tree is rooted on its first child."""
+    idx = {n: i for i, n in enumerate(names)}
+    arr = np.frombuffer("".join(rows).upper().encode(), dtype=np.uint8).reshape(len(rows), -1)
+    masks = np.full(256, (1 << 20) - 1, dtype=np.int64)
+    for i, ch in enumerate(AA):
+        masks[ord(ch)] = 1 << i
+    masks[ord("B")] = (1 << AA.index("N")) | (1 << AA.index("D"))
+    masks[ord("Z")] = (1 << AA.index("Q")) | (1 << AA.index("E"))
+    total = 0
+
+    def down(nd):
+        nonlocal total
+        kids, name, _ = nd
+        if not kids:
+            return masks[arr[idx[name]]]
+        sets = [down(k) for k in kids]
+        # resolve a multifurcation as a caterpillar rooted at the LAST child: exact for 3 children
+        # (an unrooted trifurcation), which is all the callers pass
+        cur = sets[0]
+        for s in sets[1:]:
+            inter = cur & s
+            empty = inter == 0
+            total += int(empty.sum())
+            cur = np.where(empty, cur | s, inter)
+        return cur
+    down(parse_newick(newick))
+    return total
