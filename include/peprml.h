@@ -21,6 +21,7 @@
  *                        `raxmlHPC -f d -y` -> RAxML_parsimonyTree.<run> (topology only); the caller then
  *                        runs pml_optimize on it, as the reference runs `-f e -t` (:253-272)
  *   pml_concatenate<- .../pepr/alignment/MSAConcatenator.java:78-189 (sorted taxon union, '?' padding)
+ *   pml_refine_next<- .../pepr/tree/PhylogeneticTreeRefiner.java:298-359 + AdvancedTree.java:1061-1098
  *   pml_support_tree<- .../pepr/tree/TreeSupportDecorator.java:86-163 addSupportValues(): integer
  *                        bipartition counts of the support trees written as node labels of the main tree
  *
@@ -168,6 +169,13 @@ typedef struct {
 int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *genes, const pml_model *model,
                   const pml_jackknife_opts *opts, pml_result *main_out /* newick carries the supports */,
                   char **support_newicks_out /* optional: reps lines, '\n'-separated; pml_free */);
+/* host-only: the refinement loop's support queries on a rooted Newick with support labels (")95:0.1" or
+ * ":0.1[95]"; missing = 100, fractions are x100) -- PhylogeneticTreeRefiner.java:298-359 getNextIndexToRefine,
+ * AdvancedTree.java:1061-1098 getMeanDescendantSupportValues.  *ingroup_out = comma-joined sorted leaf names of
+ * the next clade to refine, NULL if none; done[] = clades already refined in the same format (the caller's
+ * refinedSubsets).  mean_out (optional) = floor(mean descendant support) per node in order of appearance. */
+int pml_refine_next(const char *supported_newick, int cutoff, int ndone, const char *const *done,
+                    char **ingroup_out, int *nnodes_out, int **mean_out /* pml_free */);
 /* Maximum-parsimony trees (Fitch lengths on the device): randomised stepwise addition (seed 0 =
  * input order) then SPR hill climbing within spr_radius edges (0 = none; RAxML uses 20).  out[i].newick is
  * topology only; out[i].lnl / alpha / tree_length are 0; mp_length[i] (optional) = weighted Fitch length. */

@@ -288,6 +288,24 @@ int pml_support_tree(const char *main_newick, int ntrees, const char *const *sup
     return *out ? PML_OK : PML_ENOMEM;
 }
 
+int pml_refine_next(const char *newick, int cutoff, int ndone, const char *const *done, char **ingroup_out, int *nnodes_out, int **mean_out) {
+    if (!newick || !ingroup_out || ndone < 0 || (ndone > 0 && !done)) return PML_EINVAL;
+    *ingroup_out = nullptr; if (mean_out) *mean_out = nullptr; if (nnodes_out) *nnodes_out = 0;
+    try {
+        std::vector<std::string> d; for (int i = 0; i < ndone; ++i) d.push_back(done[i] ? done[i] : "");
+        std::string in, err; std::vector<int> means;
+        if (!refine_query(newick, cutoff, d, in, means, err)) { g_err = err; return PML_EPARSE; }
+        if (!in.empty() && !(*ingroup_out = dup_string(in))) return PML_ENOMEM;
+        if (nnodes_out) *nnodes_out = (int)means.size();
+        if (mean_out) {
+            *mean_out = (int *)std::malloc(sizeof(int) * std::max<size_t>(means.size(), 1));
+            if (!*mean_out) return PML_ENOMEM;
+            std::memcpy(*mean_out, means.data(), sizeof(int) * means.size());
+        }
+    } catch (const std::exception &e) { g_err = e.what(); return PML_EINVAL; }
+    return PML_OK;
+}
+
 int pml_parsimony_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const pml_parsimony_opts *opts, pml_result *out, long long *mp_length) {
     if (!ctx || !alns || !out || n <= 0) return PML_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->c.mu);

@@ -188,11 +188,11 @@ bool EncodedAlignment::encode(int nt, int ns, const char *const *nm, const char 
 namespace {
 struct RNode { std::vector<int> kids; double len = 0.1; bool haslen = false; std::string label; };
 struct Parser {
-    const char *s; size_t pos = 0; std::vector<RNode> nodes; std::string err;
+    const char *s; size_t pos = 0; std::vector<RNode> nodes; std::string err, comment;
     void ws() {
         for (;;) {
             while (s[pos] && std::isspace((unsigned char)s[pos])) ++pos;
-            if (s[pos] == '[') { while (s[pos] && s[pos] != ']') ++pos; if (s[pos]) ++pos; } else break;
+            if (s[pos] == '[') { const size_t b = pos + 1; while (s[pos] && s[pos] != ']') ++pos; comment.assign(s + b, pos - b); if (s[pos]) ++pos; } else break;
         }
     }
     bool fail(const std::string &m) { if (err.empty()) err = m + " (at char " + std::to_string(pos) + ")"; return false; }
@@ -209,7 +209,8 @@ struct Parser {
             if (end == s + pos) return fail("bad branch length");
             pos = (size_t)(end - s); nodes[id].len = v; nodes[id].haslen = true;
         }
-        ws();
+        comment.clear(); ws();
+        if (nodes[id].label.empty() && !comment.empty()) nodes[id].label = comment;      // "...:0.4[95]" support form
         return true;
     }
     int subtree(int depth) {
@@ -390,6 +391,47 @@ std::string Tree::newick_labeled(const std::vector<std::string> &names, int digi
     for (int k = 0; k < 3; ++k) { const int w = nbr[r][k]; if (w < 0 || w == 0) continue; out += ','; rec(w, r, len[r][k]); }
     out += ");";
     return out;
+}
+
+// Progressive-refinement queries on a rooted, support-labelled Newick exactly as the Java side holds it
+// (node order = order of appearance = AdvancedTree's preorder sequence, AdvancedTree.java:184-203).
+bool refine_query(const char *newick, int cutoff, const std::vector<std::string> &done, std::string &ingroup,
+                  std::vector<int> &mean_support, std::string &err) {
+    Parser P{newick};
+    const int root = P.subtree(0);
+    if (root < 0) { err = P.err; return false; }
+    const int n = (int)P.nodes.size();
+    std::vector<int> bs(n, 100);                                  // AdvancedTree.getBranchSupports :484-506
+    for (int v = 0; v < n; ++v) {
+        const RNode &nd = P.nodes[v];
+        if (nd.kids.empty() || nd.label.empty()) continue;
+        char *end; const long iv = std::strtol(nd.label.c_str(), &end, 10);
+        if (*end == 0) bs[v] = (int)iv;
+        else { const double d = std::strtod(nd.label.c_str(), &end); if (*end != 0) { err = "support label '" + nd.label + "' is not a number"; return false; } bs[v] = (int)(d * 100); }
+    }
+    std::vector<long long> sum(n, 0), cnt(n, 0);
+    mean_support.assign(n, 0);
+    std::vector<std::vector<std::string>> leaves(n);
+    for (int v = n - 1; v >= 0; --v) {                            // getMeanDescendantSupportValues :1061-1098
+        const RNode &nd = P.nodes[v];
+        if (nd.kids.empty()) { leaves[v].push_back(nd.label); continue; }
+        for (int c : nd.kids) { sum[v] += sum[c] + bs[c]; cnt[v] += cnt[c] + 1; leaves[v].insert(leaves[v].end(), leaves[c].begin(), leaves[c].end()); }
+        mean_support[v] = cnt[v] ? (int)std::floor((double)sum[v] / (double)cnt[v]) : 0;
+    }
+    ingroup.clear();
+    for (int v = 2; v < n; ++v) {                                 // getNextIndexToRefine :298-359 (0 = root, 1 = its first child)
+        const RNode &nd = P.nodes[v];
+        if (!(mean_support[v] < cutoff && bs[v] >= cutoff && (int)leaves[v].size() >= 3)) continue;
+        bool all_full = true;
+        for (int c : nd.kids) if (bs[c] < cutoff) all_full = false;
+        if (all_full) continue;
+        std::vector<std::string> l = leaves[v]; std::sort(l.begin(), l.end());
+        std::string key; for (size_t i = 0; i < l.size(); ++i) { if (i) key += ','; key += l[i]; }
+        if (std::find(done.begin(), done.end(), key) != done.end()) continue;
+        ingroup = key;
+        break;
+    }
+    return true;
 }
 
 int rf_distance(const Tree &a, const Tree &b) {

@@ -48,6 +48,12 @@ int rf_distance(const Tree &a, const Tree &b);    // (|A|+|B|-2|A&B|)/2 over non
 // counts[u][k] = number of `others` containing the bipartition of main's internal edge (u, nbr[u][k]); -1 elsewhere
 std::vector<std::vector<int>> support_counts(const Tree &main, const std::vector<Tree> &others);
 
+// PhylogeneticTreeRefiner.getNextIndexToRefine / AdvancedTree.getMeanDescendantSupportValues on a rooted
+// support-labelled Newick: ingroup = comma-joined sorted leaves of the next clade to refine ("" = none);
+// done = clades already refined (same format); mean_support per node in order of appearance
+bool refine_query(const char *newick, int cutoff, const std::vector<std::string> &done, std::string &ingroup,
+                  std::vector<int> &mean_support, std::string &err);
+
 struct EncodedAlignment {
     int ntax = 0, nsites = 0, npat = 0, mpad = 0;
     std::vector<std::string> names;

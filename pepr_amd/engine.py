@@ -282,6 +282,25 @@ def rf_distance(newick_a, newick_b):
     return rf.value
 
 
+def refine_next(supported_newick, cutoff=100, done=()):
+    """Next clade to refine (PhylogeneticTreeRefiner.getNextIndexToRefine :298-359): (sorted leaf list or None,
+    floor(mean descendant support) per node in order of appearance)."""
+    L = _lib.load()
+    n = len(done)
+    arr = (C.c_char_p * max(n, 1))(*[",".join(sorted(d)).encode() for d in done]) if n else None
+    p, nn, mp = C.c_void_p(), C.c_int(), C.c_void_p()
+    rc = L.pml_refine_next(supported_newick.encode(), cutoff, n, arr, C.byref(p), C.byref(nn), C.byref(mp))
+    if rc:
+        raise PmlError(rc, L.pml_last_error(None).decode())
+    ingroup = C.string_at(p).decode().split(",") if p else None
+    means = list(C.cast(mp, C.POINTER(C.c_int))[:nn.value]) if mp else []
+    if p:
+        L.pml_free(p)
+    if mp:
+        L.pml_free(mp)
+    return ingroup, means
+
+
 def support_tree(main_newick, support_newicks, digits=6):
     """Main tree decorated with integer bipartition counts (TreeSupportDecorator.addSupportValues)."""
     L = _lib.load()

@@ -69,3 +69,29 @@ def test_concatenate_matches_reference_rules():
     assert names == ["a", "c", "d"] and rows == ["MMM", "KKK", "LLL"]
     with pytest.raises(engine.PmlError):
         engine.concatenate(g, [7])
+
+
+def test_refine_next_follows_refiner_rules():
+    """PhylogeneticTreeRefiner.getNextIndexToRefine (:298-359) + AdvancedTree.getMeanDescendantSupportValues
+    (:1061-1098), worked by hand: supports default to 100 (tips too), mean = floor(sum/count) over ALL
+    descendants including tips; the scan starts at the third node in preorder."""
+    from pepr_amd import engine
+    nw = "((a:1,b:1)100:1,((c:1,d:1)60:1,(e:1,(f:1,g:1)100:1)100:1)100:1,h:1);"
+    ingroup, means = engine.refine_next(nw, 100)
+    # nodes in order of appearance: root, (a,b), a, b, (cdefg), (c,d), c, d, (e,(f,g)), e, (f,g), f, g, h
+    assert len(means) == 14
+    assert means[1] == 100 and means[5] == 100 and means[10] == 100
+    # (cdefg): descendants (c,d)=60, c, d, (e,(f,g))=100, e, (f,g)=100, f, g -> (60 + 7*100)/8 = 95
+    assert means[4] == 95
+    assert ingroup == ["c", "d", "e", "f", "g"]              # mean 95 < 100, own support 100, a child below cutoff
+    assert engine.refine_next(nw, 100, done=[ingroup])[0] is None
+    # cutoff 50: everything is above it
+    assert engine.refine_next(nw, 50)[0] is None
+    # bracket form and fractional supports (FastTree's 0-1 scale) read the same
+    nw2 = "((a:1,b:1):1[100],((c:1,d:1)0.6:1,(e:1,(f:1,g:1)1.0:1):1[100])1.00:1,h:1);"
+    assert engine.refine_next(nw2, 100)[0] == ["c", "d", "e", "f", "g"]
+    # the second node in preorder (first child of the root) is never offered (loop starts at index 2)
+    nw3 = "(((a:1,b:1)10:1,c:1)100:1,d:1,e:1);"
+    assert engine.refine_next(nw3, 100)[0] is None
+    with pytest.raises(engine.PmlError):
+        engine.refine_next("((a,b)x9,c);", 100)
