@@ -183,11 +183,43 @@ void Batch::destroy() {
     if (plan.d) hipFree(plan.d);
     plan = Plan();
     if (h_scalars) hipHostFree(h_scalars);
+    if (h_chain) hipHostFree(h_chain);
+    if (d_lenpool) hipFree(d_lenpool);
+    h_chain = d_chain = nullptr; d_lenpool = nullptr; chain_cap = 0;
     arena = nullptr; h_stage = d_stage = nullptr; d_frags = nullptr; d_scalars = h_scalars = nullptr;
 }
 
+int Batch::chain_sync() {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    ctx->resolve_events();
+    chain_off = 0;
+    return 0;
+}
+int Batch::chain_begin(size_t nresults) {
+    if (nresults > chain_cap) {
+        if (h_chain) hipHostFree(h_chain);
+        h_chain = d_chain = nullptr; chain_cap = 0;
+        const size_t cap = nresults * 3 / 2 + 64;
+        HIPCHK(hipHostMalloc((void **)&h_chain, cap * 4 * sizeof(double), hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void **)&d_chain, h_chain, 0));
+        chain_cap = cap;
+    }
+    if (!d_lenpool) {
+        size_t tot = 0; for (auto &G : genes) tot += (size_t)G.tree.nnodes() * 3;
+        HIPCHK(hipMalloc((void **)&d_lenpool, tot * sizeof(double)));
+        tot = 0; for (auto &G : genes) { G.d_len = d_lenpool + tot; tot += (size_t)G.tree.nnodes() * 3; }
+    }
+    for (auto &G : genes) G.len_pending.assign((size_t)G.tree.nnodes() * 3, 0);
+    // descriptors of the whole pass stay in the staging ring until the final sync: ~4 KB per (gene, step) is what
+    // run() reserves (it sizes for the worst case of 10 matrix requests per operation)
+    if (int rc = ensure_stage(std::min<size_t>(nresults * 4096 + (1 << 20), (size_t)256 << 20))) return rc;
+    chain = true; chain_off = 0;
+    return 0;
+}
 int Batch::ensure_stage(size_t bytes) {
     if (bytes <= h_cap) return 0;
+    if (chain) { if (int rc = chain_sync()) return rc; }
     const size_t cap = std::max(bytes * 3 / 2, (size_t)1 << 20);
     if (h_stage) hipHostFree(h_stage);
     if (d_stage) hipFree(d_stage);
@@ -199,6 +231,7 @@ int Batch::ensure_stage(size_t bytes) {
 }
 int Batch::ensure_frags(size_t sets) {
     if (sets <= frag_cap) return 0;
+    if (chain) { if (int rc = chain_sync()) return rc; }
     const size_t cap = std::max(sets * 5 / 4, (size_t)256);
     if (d_frags) hipFree(d_frags);
     d_frags = nullptr; frag_cap = 0; plan.valid = false;      // cached descriptors point into d_frags
@@ -329,6 +362,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     bool any_pitch = false;
     if (int rc = ensure_frags(std::max(nreq_max, (size_t)1))) return rc;
     if (nnewton > nsync_cap) {
+        if (chain) { if (int rc = chain_sync()) return rc; }
         if (d_nsync) hipFree(d_nsync);
         d_nsync = nullptr; nsync_cap = 0;
         const size_t cap = std::max(nnewton * 2, (size_t)256);
@@ -342,8 +376,11 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     const size_t o_red = align_up(o_runs + ngenes * sizeof(GeneRun), 256);
     const size_t o_newt = align_up(o_red + neval * sizeof(ReduceReq), 256);
     const size_t bytes = align_up(o_newt + nnewton * sizeof(NewtonReq), 256);
+    if (chain && chain_off + bytes > h_cap) { if (int rc = chain_sync()) return rc; }     // ring full: drain, start over
     if (int rc = ensure_stage(bytes)) return rc;
-    char *hs = (char *)h_stage, *ds = (char *)d_stage;
+    const size_t base = chain ? chain_off : 0;
+    if (chain) chain_off += bytes;
+    char *hs = (char *)h_stage + base, *ds = (char *)d_stage + base;
     PmatReq *hreq = (PmatReq *)(hs + o_req);
     NvOp *hops = (NvOp *)(hs + o_ops);
     GeneRun *hruns = (GeneRun *)(hs + o_runs);
@@ -359,6 +396,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     auto add_req = [&](size_t g, double t, int kind, int v, int q) -> const double * {
         PmatReq &r = hreq[ireq];
         r.t = t; std::memcpy(r.rates, genes[g].rates, sizeof r.rates); r.kind = kind; r.pad = 0;
+        r.tp = (chain && v >= 0 && genes[g].len_pending[(size_t)v * 3 + q]) ? genes[g].d_len + (size_t)v * 3 + q : nullptr;
         last_src.push_back({(int)g, v, q, kind});
         return d_frags + (ireq++) * FRAG_STRIDE;
     };
@@ -428,7 +466,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             if (resolve(g, t.a, L) || resolve(g, t.b, R)) return ctx->fail(-5, "internal: tail message has no slot");
             d.l = L.s; d.r = R.s; d.l_scl = L.scl; d.r_scl = R.scl;
             d.flags = L.kind | (R.kind << 2); d.mpad = mp; d.mode = t.mode;
-            double *result = d_scalars + 8 * (g * MAXTAIL + t.slot);
+            double *result = t.result_dev ? t.result_dev : d_scalars + 8 * (g * MAXTAIL + t.slot);
             if (t.mode == MODE_EVALUATE) {
                 d.pl = d.pr = add_req(g, t.t0, PM_FRAGS_PI, t.bv, t.bq);
                 d.out = G.d_patlnl[t.slot]; d.out_scl = nullptr;
@@ -443,6 +481,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
                 nr.sumtab = G.d_sumtab[t.slot]; nr.weight = G.d_weight; nr.scl = G.d_sumscl[t.slot];
                 std::memcpy(nr.rates, G.rates, sizeof nr.rates);
                 nr.t0 = t.t0; nr.tol = newton_tol; nr.out = result; nr.mpad = mp; nr.max_iter = t.max_iter;
+                nr.t_dev0 = t.t_dev0; nr.t_dev1 = t.t_dev1;
                 nr.sync = d_nsync + (size_t)in * NEWTON_SYNC_DOUBLES; newton_maxm = std::max(newton_maxm, mp);
                 algo_bytes += (double)G.aln.npat * (L.bytes + R.bytes + 640);
                 in++;
@@ -518,12 +557,14 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         ctx->toc();
     }
     const double t_launched = now_ms();
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipGetLastError());
-    const double t_done = now_ms();
     ctx->stats[K_HOST_BUILD].launches++; ctx->stats[K_HOST_BUILD].ms += t_launched - t_begin;
-    ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += t_done - t_launched;
-    ctx->resolve_events();
+    if (!chain) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipGetLastError());
+        const double t_done = now_ms();
+        ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += t_done - t_launched;
+        ctx->resolve_events();
+    }
     for (auto &o : ops) if (o.out_kind == SIDE_MSG) { Gene &G = genes[o.gene]; G.valid[o.out_id] = 1; G.pend_level[o.out_id] = -1; }
     if (record_plan) {                       // keep the descriptors of this full-traversal score
         record_plan = false;
@@ -571,12 +612,14 @@ int Batch::replay_plan(double *lnl) {
     launch_reduce((const ReduceReq *)(ds + P.o_red), (int)P.neval, ctx->stream);
     ctx->toc();
     const double t_launched = now_ms();
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipGetLastError());
-    const double t_done = now_ms();
     ctx->stats[K_HOST_BUILD].launches++; ctx->stats[K_HOST_BUILD].ms += t_launched - t_begin;
-    ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += t_done - t_launched;
-    ctx->resolve_events();
+    if (!chain) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipGetLastError());
+        const double t_done = now_ms();
+        ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += t_done - t_launched;
+        ctx->resolve_events();
+    }
     for (auto &o : P.outs) genes[o.first].valid[o.second] = 1;
     for (size_t g = 0; g < genes.size(); ++g) lnl[g] = res((int)g)[0];
     return 0;
@@ -663,24 +706,62 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
         maxlen = std::max(maxlen, order[g].size());
     }
     ++cnt_passes;
+    // The whole pass is enqueued without a host round trip: a branch optimised at step i has its new length in
+    // Gene::d_len (written by k_newton), and every later transition-matrix request across that branch reads it from
+    // there (PmatReq::tp).  The host learns the new lengths after ONE synchronisation at the end of the pass.
+    static const bool no_chain = std::getenv("PML_NO_CHAIN") != nullptr;
+    size_t nres = 0; for (int g = 0; g < n; ++g) nres += order[g].size();
+    if (!no_chain) { if (int rc = chain_begin(nres)) return rc; }
+    struct Done { int gene, v, w; double old; size_t idx; };
+    std::vector<Done> done; done.reserve(nres);
+    auto fail_out = [&](int rc) { if (chain) { chain_sync(); chain = false; } return rc; };
     for (size_t step = 0; step < maxlen; ++step) {
         ++cnt_smooth;
         std::vector<PendingOp> ops; std::vector<Tail> tails;
+        const size_t first = done.size();
         for (int g = 0; g < n; ++g) {
             if (!active[g] || step >= order[g].size()) continue;
             auto [v, w] = order[g][step];
+            Gene &G = genes[g];
             need(g, v, w, ops); need(g, w, v, ops);
-            tails.push_back({g, msg(g, v, w), msg(g, w, v), MODE_SUMTABLE, genes[g].tree.len[v][genes[g].tree.slot(v, w)], 32});
+            Tail t{g, msg(g, v, w), msg(g, w, v), MODE_SUMTABLE, G.tree.len[v][G.tree.slot(v, w)], 32};
+            if (chain) {
+                t.result_dev = d_chain + 4 * done.size();
+                t.t_dev0 = G.d_len + (size_t)v * 3 + G.tree.slot(v, w); t.t_dev1 = G.d_len + (size_t)w * 3 + G.tree.slot(w, v);
+            }
+            done.push_back({g, v, w, t.t0, done.size()});
+            tails.push_back(t);
         }
-        if (int rc = run(ops, tails)) return rc;
-        for (auto &t : tails) {
-            Gene &G = genes[t.gene];
-            auto [v, w] = order[t.gene][step];
-            const double nl = res(t.gene)[0], old = t.t0, dl = std::fabs(nl - old);
-            maxdelta[t.gene] = std::max(maxdelta[t.gene], dl);
-            if (nl != old) { G.tree.set_len(v, w, nl); branch_changed(t.gene, v, w); }
-            if (dl > thr) { std::swap(G.dirty, next[t.gene]); G.mark_node(v); G.mark_node(w); std::swap(G.dirty, next[t.gene]); }
+        if (int rc = run(ops, tails)) return fail_out(rc);
+        if (chain) {                 // the new length is on the device only: later requests across (v,w) take it from d_len
+            for (size_t i = first; i < done.size(); ++i) {
+                Gene &G = genes[done[i].gene]; const int v = done[i].v, w = done[i].w;
+                G.len_pending[(size_t)v * 3 + G.tree.slot(v, w)] = 1; G.len_pending[(size_t)w * 3 + G.tree.slot(w, v)] = 1;
+                branch_changed(done[i].gene, v, w);
+            }
+        } else {
+            for (size_t i = first; i < done.size(); ++i) {
+                Gene &G = genes[done[i].gene]; const int v = done[i].v, w = done[i].w;
+                const double nl = res(done[i].gene)[0], old = done[i].old, dl = std::fabs(nl - old);
+                maxdelta[done[i].gene] = std::max(maxdelta[done[i].gene], dl);
+                if (nl != old) { G.tree.set_len(v, w, nl); branch_changed(done[i].gene, v, w); }
+                if (dl > thr) { std::swap(G.dirty, next[done[i].gene]); G.mark_node(v); G.mark_node(w); std::swap(G.dirty, next[done[i].gene]); }
+            }
         }
+    }
+    if (chain) {
+        const double t0 = now_ms();
+        if (int rc = chain_sync()) { chain = false; return rc; }
+        ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += now_ms() - t0;
+        chain = false;
+        for (auto &d : done) {
+            Gene &G = genes[d.gene];
+            const double nl = h_chain[4 * d.idx], dl = std::fabs(nl - d.old);
+            maxdelta[d.gene] = std::max(maxdelta[d.gene], dl);
+            G.tree.set_len(d.v, d.w, nl);
+            if (dl > thr) { std::swap(G.dirty, next[d.gene]); G.mark_node(d.v); G.mark_node(d.w); std::swap(G.dirty, next[d.gene]); }
+        }
+        for (auto &G : genes) std::fill(G.len_pending.begin(), G.len_pending.end(), 0);
     }
     for (int g = 0; g < n; ++g) if (active[g]) genes[g].dirty.swap(next[g]);
     return 0;

@@ -59,6 +59,8 @@ struct Gene {
     std::vector<int> pend_level;   // scratch for collection (-1 = not pending)
     std::vector<Constraint> cons;  // topological constraints of the running search (empty = none)
     std::vector<uint8_t> dirty;    // [node*3+slot]: branch needs re-optimisation (both directions set)
+    double *d_len = nullptr;       // [node*3+slot] device copies of branch lengths written by k_newton (chained passes)
+    std::vector<uint8_t> len_pending;   // [node*3+slot]: the current length lives in d_len, the host value is stale
     void mark_node(int v) { for (int k = 0; k < 3; ++k) { const int w = tree.nbr[v][k]; if (w < 0) continue; dirty[v * 3 + k] = 1; dirty[w * 3 + tree.slot(w, v)] = 1; } }
     void mark_all() { dirty.assign((size_t)tree.nnodes() * 3, 1); }
     void mark_none() { dirty.assign((size_t)tree.nnodes() * 3, 0); }
@@ -101,6 +103,13 @@ struct Batch {
     int replay_plan(double *lnl);
     bool record_plan = false;
     std::vector<ReqSrc> last_src;
+    // chained mode: run() enqueues its copy + kernels and returns WITHOUT synchronising; descriptors are bump-
+    // allocated in the staging buffer; branch lengths optimised earlier in the chain are read from Gene::d_len
+    bool chain = false; size_t chain_off = 0;
+    double *d_lenpool = nullptr;
+    double *d_chain = nullptr, *h_chain = nullptr; size_t chain_cap = 0;     // 4 doubles per chained Newton result
+    int chain_begin(size_t nresults);
+    int chain_sync();                  // wait for everything enqueued; the staging buffer is free again
 
     int create(Ctx *c, int n, const pml_alignment_view *alns, const char *const *newicks,
                int pi_mode, int ncat, double alpha, bool score_only);
@@ -132,7 +141,9 @@ struct Batch {
     // a tail is evaluated after `after` newview ops of its gene (-1 = after all of them); `slot`
     // selects one of the gene's MAXTAIL sumtable / per-pattern-lnL / result buffers
     struct Tail { int gene; Side a, b; int mode; double t0; int max_iter; int slot = 0; int after = -1;
-                  int bv = -1, bq = 0; /* tree branch (node, slot) t0 comes from: plan replay */ };
+                  int bv = -1, bq = 0; /* tree branch (node, slot) t0 comes from: plan replay */
+                  double *result_dev = nullptr;               /* chained pass: where k_newton writes (else res(g, slot)) */
+                  double *t_dev0 = nullptr, *t_dev1 = nullptr; /* chained pass: d_len entries of the branch */ };
     double *res(int g, int slot = 0) const { return h_scalars + 8 * ((size_t)g * MAXTAIL + slot); }
     Side msg(int g, int node, int toward) const;
     bool is_cherry(int g, int node, int toward) const;

@@ -30,6 +30,8 @@ struct PmatReq {
     double rates[NCAT];
     int kind;               // PM_FRAGS, PM_FRAGS_PI (rows scaled by pi_s: root evaluation), PM_TIPTABLE
     int pad;
+    const double *tp;       // non-null: the length is read from device memory (written by an earlier k_newton of
+                            // the same stream: chained smoothing pass), `t` is ignored
 };
 enum { PM_FRAGS = 0, PM_FRAGS_PI = 1, PM_TIPTABLE = 2 };
 
@@ -90,6 +92,7 @@ struct NewtonReq {          // Newton-Raphson on one branch from its sumtable
     double tol;             // stop when |dt| < tol
     double *out;            // out[0]=t, out[1]=lnL, out[2]=d1, out[3]=d2 (at returned t)
     double *sync;           // NEWTON_SYNC_DOUBLES zeroed doubles: arrival counter + per-workgroup partial sums
+    double *t_dev0, *t_dev1; // optional: device-resident copies of the branch length (both directions) for chaining
     int mpad;
     int max_iter;           // 0: derivatives at t0 only
 };

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void k_pmat(const ModelDev *__restrict__ md,
     const int tid = threadIdx.x;
     const PmatReq req = reqs[blockIdx.x];
     for (int i = tid; i < NS * NS; i += 256) sUi[i] = md->Uinv[i];
-    if (tid < NCAT * NS) e[tid] = exp(md->eval[tid % NS] * (req.t * req.rates[tid / NS]));
+    const double tlen = req.tp ? *req.tp : req.t;
+    if (tid < NCAT * NS) e[tid] = exp(md->eval[tid % NS] * (tlen * req.rates[tid / NS]));
     __syncthreads();
     double *out = frags + (size_t)blockIdx.x * FRAG_STRIDE;
     if (tid < 3 * NCAT * NS) {
@@ -473,37 +474,75 @@ __device__ __forceinline__ double ld_agent(const double *p) {
                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
-__global__ __launch_bounds__(256) void k_newton(const ModelDev *__restrict__ md,
-                                                const NewtonReq *__restrict__ reqs, int S) {
-    __shared__ double ex[3][NCAT * NS];
+__device__ __forceinline__ double lane_swap1(double v) {      // value of the neighbouring lane (lane ^ 1), DPP quad_perm [1,0,3,2]
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// REG: the workgroup's slice is <= 128 patterns and stays in registers for the whole iteration: lane pair
+// (2j, 2j+1) owns pattern j, each lane 40 of its 80 sumtable rows (read once from HBM/L2 instead of once
+// per evaluation); the halves are combined with one DPP swap.
+__global__ __launch_bounds__(256, 3) void k_newton(const ModelDev *__restrict__ md,
+                                                   const NewtonReq *__restrict__ reqs) {
+    __shared__ double exl[NCAT * NS][2];          // (exp(lambda_i r_k t), lambda_i r_k)
     __shared__ double red[3][4];
     __shared__ double bc[4];
     const NewtonReq r = reqs[blockIdx.y];
     const int tid = threadIdx.x, mpad = r.mpad, wg = blockIdx.x;
     const size_t M = (size_t)mpad;
+    // the split depends on the request alone (not on what else is in the launch): results are reproducible
+    // whatever the batch composition
+    const int S = min(NEWTON_MAX_SPLIT, (mpad + 127) / 128);
+    if (wg >= S) return;
     const int slice = ((mpad / 32 + S - 1) / S) * 32;
+    const bool REG = slice <= 128;
     const int p_begin = wg * slice, p_end = min(mpad, p_begin + slice);
     unsigned *cnt = reinterpret_cast<unsigned *>(r.sync);
     double *part = r.sync + 2;
     int nevals = 0;
     bool failed = false;
+    double xr[CLV_ROWS / 2]; double rw = 0.0, rscl = 0.0; const int rhalf = tid & 1;
+    if (REG) {
+        const int p = p_begin + (tid >> 1);
+        if (p < p_end) { rw = r.weight[p]; rscl = (double)r.scl[p]; }
+#pragma unroll
+        for (int i = 0; i < CLV_ROWS / 2; ++i) xr[i] = (rw != 0.0) ? r.sumtab[(size_t)(rhalf * (CLV_ROWS / 2) + i) * M + p] : 0.0;
+    }
 
     auto eval_at = [&](double t, double &L, double &d1, double &d2) {
         if (tid < NCAT * NS) {
             const double lr = md->eval[tid % NS] * r.rates[tid / NS];
-            const double e = exp(lr * t);
-            ex[0][tid] = e; ex[1][tid] = lr * e; ex[2][tid] = lr * lr * e;
+            exl[tid][0] = exp(lr * t); exl[tid][1] = lr;
         }
         __syncthreads();
         double acc[3] = {0.0, 0.0, 0.0};
+        if (REG) {
+            double f = 0.0, f1 = 0.0, f2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < CLV_ROWS / 2; ++i) {
+                const int row = rhalf * (CLV_ROWS / 2) + i;
+                const double xe = xr[i] * exl[row][0], xl = xe * exl[row][1];
+                f += xe; f1 += xl; f2 += xl * exl[row][1];
+                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);      // at most 8 LDS pairs in flight
+            }
+            f += lane_swap1(f); f1 += lane_swap1(f1); f2 += lane_swap1(f2);
+            if (rhalf == 0 && rw != 0.0) {
+                const double r1 = f1 / f;
+                acc[0] = rw * (log(f * 0.25) - rscl * LOG_2_256);
+                acc[1] = rw * r1;
+                acc[2] = rw * (f2 / f - r1 * r1);
+            }
+        } else
         for (int p = p_begin + tid; p < p_end; p += 256) {
             const double w = r.weight[p];
             if (w == 0.0) continue;
             double f = 0.0, f1 = 0.0, f2 = 0.0;
 #pragma unroll 16
             for (int row = 0; row < CLV_ROWS; ++row) {
-                const double x = r.sumtab[(size_t)row * M + p];
-                f += x * ex[0][row]; f1 += x * ex[1][row]; f2 += x * ex[2][row];
+                const double xe = r.sumtab[(size_t)row * M + p] * exl[row][0], xl = xe * exl[row][1];
+                f += xe; f1 += xl; f2 += xl * exl[row][1];
             }
             const double r1 = f1 / f;
             acc[0] += w * (log(f * 0.25) - r.scl[p] * LOG_2_256);
@@ -541,30 +580,31 @@ __global__ __launch_bounds__(256) void k_newton(const ModelDev *__restrict__ md,
     __syncthreads();
     double t = r.t0;
     if (r.max_iter > 0) t = t < PML_TMIN ? PML_TMIN : (t > PML_TMAX ? PML_TMAX : t);
-    double L, d1, d2;
-    eval_at(t, L, d1, d2);
-    for (int it = 0; it < r.max_iter && !failed; ++it) {
+    double L = 0.0, d1 = 0.0, d2 = 0.0, tn = t;
+    bool first = true;
+    int it = 0, bt = 0;
+    for (;;) {                                          // one evaluation site: initial point, Newton steps and backtracks
+        double Ln, n1, n2;
+        eval_at(tn, Ln, n1, n2);
+        if (first) { first = false; L = Ln; d1 = n1; d2 = n2; }
+        else {
+            if (!(failed || Ln >= L - 1e-9 || bt >= 8)) { ++bt; tn = 0.5 * (tn + t); tn = tn < PML_TMIN ? PML_TMIN : (tn > PML_TMAX ? PML_TMAX : tn); continue; }
+            if (failed || Ln < L - 1e-9) break;
+            const double dt = fabs(tn - t);
+            t = tn; L = Ln; d1 = n1; d2 = n2; ++it;
+            if (dt < r.tol) break;
+        }
+        if (it >= r.max_iter || failed) break;
         const double step = (d2 < 0.0) ? -d1 / d2 : (d1 > 0.0 ? t : -0.5 * t);
-        double tn = t + step, Ln, n1, n2;
-        int bt = 0;
-        if (fabs(step) < r.tol && d2 < 0.0) {       // converged: take the (sub-tolerance) step unevaluated
-            t = tn < PML_TMIN ? PML_TMIN : (tn > PML_TMAX ? PML_TMAX : tn);
-            break;
-        }
-        for (;;) {
-            tn = tn < PML_TMIN ? PML_TMIN : (tn > PML_TMAX ? PML_TMAX : tn);
-            eval_at(tn, Ln, n1, n2);
-            if (failed || Ln >= L - 1e-9 || bt >= 8) break;
-            ++bt; tn = 0.5 * (tn + t);
-        }
-        if (failed || Ln < L - 1e-9) break;
-        const double dt = fabs(tn - t);
-        t = tn; L = Ln; d1 = n1; d2 = n2;
-        if (dt < r.tol) break;
+        tn = t + step; bt = 0;
+        const bool tiny = fabs(step) < r.tol && d2 < 0.0;   // converged: take the (sub-tolerance) step unevaluated
+        tn = tn < PML_TMIN ? PML_TMIN : (tn > PML_TMAX ? PML_TMAX : tn);
+        if (tiny) { t = tn; break; }
     }
     if (tid == 0 && wg == 0) {
         if (failed) { t = r.t0; L = __builtin_nan(""); }
         r.out[0] = t; r.out[1] = L; r.out[2] = d1; r.out[3] = d2;
+        if (r.t_dev0) { *r.t_dev0 = t; *r.t_dev1 = t; }
     }
 }
 
@@ -606,12 +646,12 @@ void launch_reduce(const ReduceReq *reqs, int n, hipStream_t s) {
 }
 void launch_newton(const ModelDev *model, const NewtonReq *reqs, int n, int max_mpad, hipStream_t s) {
     if (n <= 0) return;
-    int S = max_mpad / 128;
+    int S = (max_mpad + 127) / 128;       // grid width; each request uses its own split (k_newton)
     S = S < 1 ? 1 : (S > NEWTON_MAX_SPLIT ? NEWTON_MAX_SPLIT : S);
     const int chunk = 1024 / S;          // S * chunk workgroups of 256 threads are co-resident on 256 CUs
     for (int off = 0; off < n; off += chunk) {
         const int m = (n - off < chunk) ? n - off : chunk;
-        hipLaunchKernelGGL(k_newton, dim3(S, m), dim3(256), 0, s, model, reqs + off, S);
+        hipLaunchKernelGGL(k_newton, dim3(S, m), dim3(256), 0, s, model, reqs + off);
     }
 }
 
