@@ -124,7 +124,8 @@ def main():
     # optimisation, NNI hill climbing), every gene of the shard, one batched call
     search = None
     if not args.no_search:
-        sb = engine.Batch(ctx, [(g[0], g[1]) for g in genes], None, alpha=1.0)
+        sctx = engine.Context(local)           # no per-kernel HIP events in the timed search
+        sb = engine.Batch(sctx, [(g[0], g[1]) for g in genes], None, alpha=1.0)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -135,7 +136,7 @@ def main():
             dist.barrier()
         sdt = time.perf_counter() - ts
         rf = [engine.rf_distance(genes[i][2], sb.newick(i)) for i in range(len(genes))]
-        sb.close()
+        sb.close(); sctx.close()
         if world > 1:
             t = torch.tensor([sdt], dtype=torch.float64, device=pd._device())
             dist.all_reduce(t, op=dist.ReduceOp.MAX); sdt = float(t[0])

@@ -20,6 +20,7 @@
  *   pml_parsimony  <- .../pepr/tree/RAxMLRunner.java:215-251  runRaxmlParsimonyWithBranchLengths():
  *                        `raxmlHPC -f d -y` -> RAxML_parsimonyTree.<run> (topology only); the caller then
  *                        runs pml_optimize on it, as the reference runs `-f e -t` (:253-272)
+ *   pml_bootstrap  <- .../pepr/tree/RAxMLRunner.java:115-132,302-318 (`-f a -x -N`, bootstrapReps > 0)
  *   pml_concatenate<- .../pepr/alignment/MSAConcatenator.java:78-189 (sorted taxon union, '?' padding)
  *   pml_refine_next<- .../pepr/tree/PhylogeneticTreeRefiner.java:298-359 + AdvancedTree.java:1061-1098
  *   pml_support_tree<- .../pepr/tree/TreeSupportDecorator.java:86-163 addSupportValues(): integer
@@ -183,6 +184,12 @@ typedef struct { unsigned seed; int spr_radius; } pml_parsimony_opts;
 int pml_parsimony(pml_ctx *ctx, const pml_alignment *aln, const pml_parsimony_opts *opts, pml_result *out, long long *mp_length);
 int pml_parsimony_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const pml_parsimony_opts *opts,
                         pml_result *out, long long *mp_length);
+/* Non-parametric bootstrap (`raxmlHPC -f a -x seed -N reps`, RAxMLRunner.java:115-132): best ML tree (NNI + SPR)
+ * labelled with the percentage of `reps` column-resampled replicate trees (one device batch) containing each
+ * bipartition, as RAxML_bipartitions.<run> carries them (read at RAxMLRunner.java:302-318). */
+int pml_bootstrap(pml_ctx *ctx, const pml_alignment *aln, const pml_model *model, int reps, unsigned long long seed,
+                  int spr_radius_best, double epsilon, pml_result *best_out,
+                  char **replicate_newicks_out /* optional: reps lines; pml_free */);
 /* host-only: FASTA text (">taxon\nSEQ\n" per taxon, SequenceAlignment.java:405-416) of the
  * concatenation of the selected genes (sel == NULL: all), taxa = sorted union, '?' padding */
 int pml_concatenate(int ngenes, const pml_alignment *genes, int nsel, const int *sel, char **fasta_out);

@@ -141,3 +141,58 @@ extern "C" int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *gene
     catch (const std::exception &e) { return ctx->c.fail(PML_EINVAL, e.what()); }
     return PML_OK;
 }
+
+// Non-parametric bootstrap (`raxmlHPC -f a -x seed -N reps`, RAxMLRunner.java:115-132 with reps > 0): best ML tree
+// of the alignment (NNI + lazy SPR) and `reps` trees of column-resampled alignments (NNI), searched as ONE device
+// batch; the best tree carries the percentage of replicates containing each bipartition (RAxML_bipartitions.<n>).
+// RAxML's "rapid" heuristics (CAT approximation, tree reuse between replicates) are not restated: each replicate
+// gets a full search, which is what those heuristics approximate.
+extern "C" int pml_bootstrap(pml_ctx *ctx, const pml_alignment *aln, const pml_model *model, int reps, unsigned long long seed,
+                             int spr_radius_best, double epsilon, pml_result *best_out, char **replicate_newicks_out) {
+    if (!ctx || !aln || !best_out || reps < 0 || aln->ntax < 3 || aln->nsites < 1) return PML_EINVAL;
+    std::memset(best_out, 0, sizeof *best_out);
+    if (replicate_newicks_out) *replicate_newicks_out = nullptr;
+    const double eps = epsilon > 0 ? epsilon : 1e-3;
+    std::lock_guard<std::mutex> lk(ctx->c.mu);
+    try {
+        const int ncat = model ? model->ncat : 4, pm = model ? model->pi_mode : 0;
+        const double alpha = model ? model->alpha : 1.0;
+        const int n = aln->ntax, L = aln->nsites;
+        Tree best; std::vector<std::string> names; double lnl = 0, al = alpha; int npat = 0;
+        {
+            pml_alignment_view v{n, L, aln->names, aln->rows};
+            Batch b; int rc = b.create(&ctx->c, 1, &v, nullptr, pm, ncat, alpha, false);
+            if (!rc) rc = b.search(true, spr_radius_best, true, eps, &lnl);
+            if (rc) { b.destroy(); return rc; }
+            best = b.genes[0].tree; names = b.genes[0].aln.names; al = b.genes[0].alpha; npat = b.genes[0].aln.npat;
+            b.destroy();
+        }
+        std::vector<Tree> trees((size_t)reps); std::string txt;
+        if (reps > 0) {
+            std::mt19937_64 rng(seed);
+            std::vector<std::vector<std::string>> rows((size_t)reps, std::vector<std::string>((size_t)n, std::string((size_t)L, '-')));
+            std::vector<int> col((size_t)L);
+            for (int r = 0; r < reps; ++r) {
+                for (int s = 0; s < L; ++s) col[s] = (int)(rng() % (uint64_t)L);
+                for (int i = 0; i < n; ++i) { const char *src = aln->rows[i]; std::string &dst = rows[r][i]; for (int s = 0; s < L; ++s) dst[s] = src[col[s]]; }
+            }
+            std::vector<std::vector<const char *>> rps((size_t)reps);
+            std::vector<pml_alignment_view> vs((size_t)reps);
+            for (int r = 0; r < reps; ++r) { for (auto &x : rows[r]) rps[r].push_back(x.c_str()); vs[r] = pml_alignment_view{n, L, aln->names, rps[r].data()}; }
+            Batch b; int rc = b.create(&ctx->c, reps, vs.data(), nullptr, pm, ncat, alpha, false);
+            std::vector<double> l((size_t)reps);
+            if (!rc) rc = b.search(true, 0, true, eps, l.data());
+            if (rc) { b.destroy(); return rc; }
+            for (int r = 0; r < reps; ++r) { trees[r] = b.genes[r].tree; txt += b.genes[r].tree.newick(names, 6); txt += '\n'; }
+            b.destroy();
+        }
+        auto counts = support_counts(best, trees);
+        if (reps > 0) for (auto &row : counts) for (int &c : row) if (c >= 0) c = (int)(0.5 + 100.0 * c / reps);   // percent, as RAxML_bipartitions
+        best_out->lnl = lnl; best_out->alpha = al; best_out->tree_length = best.length(); best_out->npatterns = npat; best_out->nsites = L;
+        best_out->newick = dup_cstr(reps > 0 ? best.newick_labeled(names, 6, counts) : best.newick(names, 6));
+        if (replicate_newicks_out) *replicate_newicks_out = dup_cstr(txt);
+        if (!best_out->newick) return ctx->c.fail(PML_ENOMEM, "host allocation failed");
+    } catch (const std::bad_alloc &) { return ctx->c.fail(PML_ENOMEM, "host allocation failed"); }
+    catch (const std::exception &e) { return ctx->c.fail(PML_EINVAL, e.what()); }
+    return PML_OK;
+}

@@ -94,7 +94,7 @@ int main(int argc, char **argv) {
     pml_ctx *ctx = nullptr; pml_config cfg = {0, 0, 0};
     if (int rc = pml_create(&cfg, &ctx)) return fail(tool, std::string("engine: ") + pml_strerror(rc) + " " + pml_last_error(nullptr));
     std::vector<const char *> np, rp; pml_alignment v = view(a, np, rp);
-    pml_model model = {4, 1.0, PML_PI_RAXML_3DP};
+    pml_model model = {4, 1.0, PML_PI_WAG_FULL};           // FastTree_WAG holds the 7-digit WAG frequencies
     pml_search_opts opts = {1, 1, 0, 1e-3, 0};         // NJ start + NNI rounds, as FastTree's ML stage
     Aln cons; std::vector<const char *> cnp, crp;
     if (cons_file) {                                   // FastTreeRunner.java:54-64: FASTA of 0/1/- rows
@@ -119,7 +119,7 @@ int main(int argc, char **argv) {
 int main(int argc, char **argv) {
     const char *tool = "raxmlHPC";
     std::string f = "d", model_s = "PROTGAMMAWAG", aln_f, run, tree_f, trees_f;
-    bool pars_only = false; unsigned seed = 12345;
+    bool pars_only = false; unsigned seed = 12345; unsigned long long bs_seed = 12345; int bs_reps = 0;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto val = [&](std::string &dst) { if (i + 1 >= argc) return false; dst = argv[++i]; return true; };
@@ -134,7 +134,8 @@ int main(int argc, char **argv) {
         else if (a == "-p") { if (!val(dummy)) return fail(tool, a + " needs a value"); seed = (unsigned)std::strtoul(dummy.c_str(), nullptr, 10); }
         else if (a == "-y") pars_only = true;              // RAxMLRunner.java:134-140,241-251: parsimony start tree only
         else if (a == "-Y") return fail(tool, "parsimony bootstrap (-Y -N) is not built");
-        else if (a == "-x" || a == "-N") return fail(tool, "rapid bootstrap (-f a -x -N) is not built; PEPR's jackknife uses reps=0");
+        else if (a == "-x") { if (!val(dummy)) return fail(tool, "-x needs a value"); bs_seed = std::strtoull(dummy.c_str(), nullptr, 10); }
+        else if (a == "-N" || a == "-#") { if (!val(dummy)) return fail(tool, a + " needs a value"); bs_reps = std::atoi(dummy.c_str()); }
         else return fail(tool, "unknown option " + a);
     }
     if (aln_f.empty() || run.empty()) return fail(tool, "usage: raxmlHPC -f d|e|g -m PROTGAMMAWAG -s aln.phy -n run [-t tree] [-z trees]");
@@ -149,7 +150,21 @@ int main(int argc, char **argv) {
     std::ofstream info("RAxML_info." + run), logf("RAxML_log." + run);
     info << "peprml raxmlHPC shim (MI355X HIP engine), model " << model_s << ", alignment " << aln_f << "\n";
     int rc = 0;
-    if (f == "d" && pars_only) {
+    if (f == "a") {                                       // RAxMLRunner.java:115-132 with bootstrapReps > 0
+        if (bs_reps <= 0) { pml_destroy(ctx); return fail(tool, "-f a needs -x seed -N reps"); }
+        pml_result res; char *reps_txt = nullptr;
+        rc = pml_bootstrap(ctx, &v, &model, bs_reps, bs_seed, 5, 1e-3, &res, &reps_txt);
+        if (!rc) {
+            std::ofstream("RAxML_bipartitions." + run) << reformat(res.newick, 20, true) << "\n";   // read at RAxMLRunner.java:302-318
+            std::ofstream("RAxML_bootstrap." + run) << reps_txt;
+            char b[256]; std::snprintf(b, sizeof b, "Final ML Optimization Likelihood: %.6f\nalpha: %.6f\n", res.lnl, res.alpha);
+            info << b;
+            // best tree without the support labels
+            std::string plain; for (const char *p = res.newick; *p; ++p) { plain += *p; if (*p == ')') { while (std::isdigit((unsigned char)p[1])) ++p; } }
+            std::ofstream("RAxML_bestTree." + run) << reformat(plain.c_str(), 20, true) << "\n";
+            pml_free(reps_txt); pml_result_free(&res);
+        }
+    } else if (f == "d" && pars_only) {
         pml_parsimony_opts po = {seed, 20};
         pml_result res; long long mp = 0;
         rc = pml_parsimony(ctx, &v, &po, &res, &mp);
@@ -202,7 +217,7 @@ int main(int argc, char **argv) {
             }
             pml_result_free(&o);
         }
-    } else { pml_destroy(ctx); return fail(tool, "-f " + f + " is not built (d, e, g are)"); }
+    } else { pml_destroy(ctx); return fail(tool, "-f " + f + " is not built (a, d, e, g are)"); }
     if (rc) { std::string m = pml_last_error(ctx); pml_destroy(ctx); return fail(tool, m); }
     pml_destroy(ctx);
     return 0;

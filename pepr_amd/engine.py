@@ -152,6 +152,21 @@ class Context:
         o = _opts(optimize_alpha, nni, spr_radius, epsilon, constraints=constraints)
         return self._oneshot(self.L.pml_search_batch, genes, start_newicks, _model(ncat, alpha, pi_mode), (C.byref(o),))
 
+    def bootstrap(self, gene, reps=100, seed=1, spr_radius=5, epsilon=1e-3, alpha=1.0, ncat=4, pi_mode=PI_RAXML_3DP):
+        """`raxmlHPC -f a -x seed -N reps`: best ML tree with percent supports + the replicate trees."""
+        keep = []
+        a = _aln_struct(gene[0], gene[1], keep)
+        m = _model(ncat, alpha, pi_mode)
+        res, rep = _lib.Result(), C.c_void_p()
+        rc = self.L.pml_bootstrap(self.ptr, C.byref(a), C.byref(m), reps, seed, spr_radius, epsilon, C.byref(res), C.byref(rep))
+        self._check(rc)
+        out = {"lnl": res.lnl, "alpha": res.alpha, "tree_length": res.tree_length, "newick": C.string_at(res.newick).decode(),
+               "replicates": C.string_at(rep).decode().splitlines() if rep else []}
+        self.L.pml_result_free(C.byref(res))
+        if rep:
+            self.L.pml_free(rep)
+        return out
+
     def parsimony(self, genes, seed=0, spr_radius=20):
         """`raxmlHPC -y` start trees (RAxMLRunner.java:215-251): list of {"newick" (topology only), "length"}."""
         keep = []

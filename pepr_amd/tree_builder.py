@@ -11,8 +11,8 @@ read like the reference's own call sites; every `run()` goes through the C ABI
 Behaviour kept from the reference: a failed build leaves the result `None` (FastTreeRunner.java:
 125-131 logs and continues; callers see a null tree string); the ML matrix is a RAxML model
 string (default PROTGAMMAWAG, PhylogenomicPipeline2.java:248-250); threads/processes are accepted
-and ignored (the GPU engine needs no -T).  Not mirrored (out of scope): rapid
-bootstrap (-f a), parsimony bootstrap (-Y), nucleotide (-gtr -nt).
+and ignored (the GPU engine needs no -T).  Not mirrored (out of scope): parsimony
+bootstrap (-Y), nucleotide (-gtr -nt), FastTree's SH-like local supports (bootstrapReps > 0 there).
 """
 import logging
 
@@ -72,6 +72,7 @@ class RAxMLRunner:
         self.algorithm = 0            # 1 = parsimony only, 2 = parsimony + ML lengths (RAxMLRunner.java:28-29)
         self.parsimonyTree = None
         self.parsimonyWithBLTree = None
+        self.bestTreeWithSupports = None
         self.seed = 12345
 
     def setAlignment(self, a):
@@ -131,8 +132,11 @@ class RAxMLRunner:
                     o = ctx.optimize([gene], [p["newick"]], **mdl)[0]
                     self.parsimonyWithBLTree, self.lnl, self.alpha = o["newick"], o["lnl"], o["alpha"]
                 return
-            if self.bootstrapReps:
-                raise ValueError("rapid bootstrap (-f a) is not on the GPU path; PEPR's jackknife uses reps=0")
+            if self.bootstrapReps:                                                # -f a -x <odd seed> -N reps
+                r = ctx.bootstrap(gene, reps=self.bootstrapReps, seed=self.seed | 1, spr_radius=self.spr_radius, **mdl)
+                self.bestTreeWithSupports, self.lnl, self.alpha = r["newick"], r["lnl"], r["alpha"]
+                self.bestTree = None                                              # -f a writes no RAxML_result
+                return
             r = ctx.search([gene], None, spr_radius=self.spr_radius, **mdl)[0]
             self.bestTree, self.lnl, self.alpha = r["newick"], r["lnl"], r["alpha"]
         except Exception as e:          # reference: rc logged, result stays null
@@ -141,6 +145,9 @@ class RAxMLRunner:
 
     def getBestTree(self):
         return self.bestTree
+
+    def getBestTreeWithSupports(self):      # RAxML_bipartitions.<run>, RAxMLRunner.java:302-318
+        return self.bestTreeWithSupports
 
     def getPerSiteLLs(self):
         return self.perSiteLLs
@@ -207,7 +214,8 @@ class FastTreeRunner:
         """`FastTree_WAG -gamma -nosupport`: NJ start + NNI hill climbing under WAG+Gamma."""
         ctx = self.ctx or default_context()
         try:
-            r = ctx.search([self.alignment.as_gene()], None, nni=True, spr_radius=0, pi_mode=engine.PI_RAXML_3DP,
+            # FastTree_WAG carries the full-precision WAG frequencies, RAxML the 3-decimal ones (SURVEY 8c)
+            r = ctx.search([self.alignment.as_gene()], None, nni=True, spr_radius=0, pi_mode=engine.PI_WAG_FULL,
                            constraints=self._constraint_matrix())[0]
             self.result, self.lnl = r["newick"], r["lnl"]
         except Exception as e:
@@ -279,7 +287,7 @@ class PhylogeneticTreeBuilder:
             r = RAxMLRunner(self.processes, self.ctx)
             r.setBootstrapReps(self.bootstrapReps); r.setAlignment(self.alignment); r.setMatrix(self.mlMatrix)
             r.run()
-            self.setTreeString(r.getBestTree())
+            self.setTreeString(r.getBestTree() if self.bootstrapReps == 0 else r.getBestTreeWithSupports())
         elif self.treeBuildingMethod in (PARSIMONY, PARSIMONY_BL):        # PhylogeneticTreeBuilder.java:136-161
             r = RAxMLRunner(self.processes, self.ctx)
             if self.treeBuildingMethod == PARSIMONY:

@@ -32,10 +32,10 @@ def test_fasttree_shim(tmp_path, gpu_ctx):
     assert r.returncode == 0, r.stderr
     tree = r.stdout.splitlines()[0]               # FastTreeRunner.java:95-96: stdout line 0 is the tree
     assert tree.endswith(");") and "LogLk" in r.stderr
-    ref = gpu_ctx.search([(names, rows)], None, nni=True, spr_radius=0)[0]
+    ref = gpu_ctx.search([(names, rows)], None, nni=True, spr_radius=0, pi_mode=engine.PI_WAG_FULL)[0]
     assert engine.rf_distance(tree, ref["newick"]) == 0
     # 5-decimal lengths as FastTree prints them: rescoring loses < 0.05 lnL
-    again = gpu_ctx.score([(names, rows)], [tree], alpha=ref["alpha"])[0]["lnl"]
+    again = gpu_ctx.score([(names, rows)], [tree], alpha=ref["alpha"], pi_mode=engine.PI_WAG_FULL)[0]["lnl"]
     assert abs(again - ref["lnl"]) < 0.05
 
 
@@ -71,3 +71,40 @@ def test_raxml_shim_modes(tmp_path, gpu_ctx):
     assert engine.rf_distance(best, sref["newick"]) == 0
     # same run name again is refused
     assert run(["-f", "d", "-m", "PROTGAMMAWAG", "-s", "g.phy", "-n", "d1"]).returncode != 0
+
+
+def test_bootstrap_api_shim_and_mirror(tmp_path, gpu_ctx):
+    """`-f a -x seed -N reps` (RAxMLRunner.java:115-132, bootstrapReps > 0): supports are percentages of
+    column-resampled replicate trees; files as SURVEY Appendix A lists them (no RAxML_result)."""
+    import re
+    from pepr_amd import tree_builder as tb
+    import util
+    names, rows, nw = synth.simulate_alignment(10, 400, 73)
+    r = gpu_ctx.bootstrap((names, rows), reps=20, seed=7)
+    assert len(r["replicates"]) == 20
+    labels = [int(x) for x in re.findall(r"\)(\d+):", r["newick"])]
+    assert len(labels) == 10 - 3 and all(0 <= v <= 100 for v in labels)
+    # each label is exactly the share of replicates that contain the split
+    main_splits = util.splits(re.sub(r"\)\d+:", "):", r["newick"]))
+    rep_splits = [util.splits(t) for t in r["replicates"]]
+    counts = sorted(int(0.5 + 100.0 * sum(s in rs or (frozenset(names) - s) in rs for rs in rep_splits) / 20) for s in main_splits
+                    if 1 < len(s) < len(names) - 1)
+    assert counts == sorted(labels)
+    assert gpu_ctx.bootstrap((names, rows), reps=20, seed=7)["newick"] == r["newick"]          # seeded
+    assert sum(labels) / len(labels) > 60                                                      # 400 sites: mostly well supported
+    plain = gpu_ctx.search([(names, rows)], None, nni=True, spr_radius=5)[0]
+    assert engine.rf_distance(re.sub(r"\)\d+:", "):", r["newick"]), plain["newick"]) == 0
+    # shim
+    _write(tmp_path, names, rows)
+    p = subprocess.run([RX, "-f", "a", "-m", "PROTGAMMAWAG", "-s", "g.phy", "-n", "bs", "-x", "12345", "-N", "10"],
+                       cwd=tmp_path, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    bip = open(tmp_path / "RAxML_bipartitions.bs").read().strip()
+    assert re.search(r"\)\d+:", bip) and bip.endswith(":0.0;")
+    assert len(open(tmp_path / "RAxML_bootstrap.bs").read().splitlines()) == 10
+    assert os.path.exists(tmp_path / "RAxML_bestTree.bs") and not os.path.exists(tmp_path / "RAxML_result.bs")
+    assert ")" in open(tmp_path / "RAxML_bestTree.bs").read() and not re.search(r"\)\d+:", open(tmp_path / "RAxML_bestTree.bs").read())
+    # mirror: PhylogeneticTreeBuilder with bootstrapReps > 0 returns the supported tree (PhylogeneticTreeBuilder.java:175-179)
+    b = tb.PhylogeneticTreeBuilder(gpu_ctx)
+    b.setAlignment(tb.SequenceAlignment(names, rows)); b.setTreeBuildingMethod(tb.ML); b.setBootstrapReps(5); b.run()
+    assert re.search(r"\)\d+:", b.getTreeString())

@@ -7,7 +7,7 @@ ng = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 nt = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 ns = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 spr = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-ctx = engine.Context(0, profile=True)
+ctx = engine.Context(0, profile=not os.environ.get("NO_PROFILE"))
 genes = synth.simulate_genes(ng, nt, ns)
 G = [(g[0], g[1]) for g in genes]
 t0 = time.time(); b = engine.Batch(ctx, G, None, alpha=1.0); print("create (NJ start) %.2fs" % (time.time() - t0), flush=True)
