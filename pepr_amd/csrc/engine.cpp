@@ -104,9 +104,6 @@ int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *con
     if (int rc = ctx->ensure_model(pm)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     genes.resize(n);
-    std::string err;
-    size_t total = 0;
-    std::vector<size_t> off(n);
     {   // encode / parse / NJ are independent per gene: host threads (plain std::thread, no GPU work)
         const int nthreads = std::max(1, std::min({n, 16, (int)std::thread::hardware_concurrency()}));
         std::vector<std::string> errs(n);
@@ -127,6 +124,15 @@ int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *con
         for (auto &t : pool) t.join();
         for (int g = 0; g < n; ++g) if (!errs[g].empty()) return ctx->fail(-2, "gene " + std::to_string(g) + ": " + errs[g]);
     }
+    return layout(alpha, score_only);
+}
+
+// device arena + per-gene pointers from (ntax, mpad) alone; host-encoded codes/weights are uploaded when present
+// (replicates built by create_replicates() have none: k_gather fills them)
+int Batch::layout(double alpha, bool score_only) {
+    const int n = (int)genes.size();
+    size_t total = 0;
+    std::vector<size_t> off(n);
     for (int g = 0; g < n; ++g) {
         Gene &G = genes[g];
         const int nt = G.aln.ntax, mp = G.aln.mpad, ndir = 3 * (nt - 2);
@@ -158,8 +164,10 @@ int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *con
         for (int k = 0; k < MAXTAIL; ++k) { G.d_sumtab[k] = (double *)p; p += (size_t)CLV_ROWS * mp * 8; }
         for (int k = 0; k < MAXTAIL; ++k) { G.d_sumscl[k] = (int *)p; p += align_up((size_t)mp * 4, 256); }
         for (int k = 0; k < MAXTAIL; ++k) { G.d_patlnl[k] = (double *)p; p += align_up((size_t)mp * 8, 256); }
-        HIPCHK(hipMemcpyAsync(G.d_codes, G.aln.codes.data(), (size_t)nt * mp, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(G.d_weight, G.aln.weight.data(), (size_t)mp * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (!G.aln.codes.empty()) {
+            HIPCHK(hipMemcpyAsync(G.d_codes, G.aln.codes.data(), (size_t)nt * mp, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipMemcpyAsync(G.d_weight, G.aln.weight.data(), (size_t)mp * 8, hipMemcpyHostToDevice, ctx->stream));
+        }
         set_alpha(g, alpha);
     }
     // results (8 doubles per gene) are written by the kernels straight into mapped pinned host
@@ -187,6 +195,108 @@ void Batch::destroy() {
     if (d_lenpool) hipFree(d_lenpool);
     h_chain = d_chain = nullptr; d_lenpool = nullptr; chain_cap = 0;
     arena = nullptr; h_stage = d_stage = nullptr; d_frags = nullptr; d_scalars = h_scalars = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------
+// GeneStore / create_replicates: jackknife concatenation on the device
+// ------------------------------------------------------------------------------------------
+int GeneStore::create(Ctx *c, int n, const pml_alignment_view *alns) {
+    ctx = c;
+    HIPCHK(hipSetDevice(ctx->device));
+    items.resize(n);
+    std::vector<std::string> errs(n);
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (int g = next++; g < n; g = next++) {
+            try { if (items[g].aln.encode(alns[g].ntax, alns[g].nsites, alns[g].names, alns[g].rows, errs[g])) pair_counts(items[g].aln, items[g].cmp, items[g].diff); }
+            catch (const std::exception &e) { errs[g] = e.what(); }
+        }
+    };
+    const int nthreads = std::max(1, std::min({n, 16, (int)std::thread::hardware_concurrency()}));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    for (int g = 0; g < n; ++g) if (!errs[g].empty()) return ctx->fail(-2, "gene " + std::to_string(g) + ": " + errs[g]);
+    size_t total = 0;
+    for (auto &it : items) total += align_up((size_t)it.aln.ntax * it.aln.mpad, 256) + align_up((size_t)it.aln.mpad * 8, 256);
+    if (hipMalloc((void **)&arena, total) != hipSuccess) { arena = nullptr; return ctx->fail(-4, "gene store does not fit on the device"); }
+    char *p = arena;
+    for (auto &it : items) {
+        it.d_codes = (uint8_t *)p; p += align_up((size_t)it.aln.ntax * it.aln.mpad, 256);
+        it.d_w = (double *)p; p += align_up((size_t)it.aln.mpad * 8, 256);
+        HIPCHK(hipMemcpyAsync(it.d_codes, it.aln.codes.data(), (size_t)it.aln.ntax * it.aln.mpad, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(it.d_w, it.aln.weight.data(), (size_t)it.aln.mpad * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+void GeneStore::destroy() { if (arena) { hipSetDevice(ctx->device); hipFree(arena); arena = nullptr; } items.clear(); }
+
+int Batch::create_replicates(Ctx *c, const GeneStore &store, const std::vector<std::vector<int>> &sel, int pm, int nc, double alpha) {
+    ctx = c; pi_mode = pm; ncat = nc; score_only_batch = false;
+    virtual_cherries = std::getenv("PML_NO_CHERRY") == nullptr;
+    virtual_pitch = virtual_cherries && std::getenv("PML_NO_PITCH") == nullptr;
+    const int n = (int)sel.size();
+    if (n <= 0) return ctx->fail(-1, "empty batch");
+    if (int rc = ctx->ensure_model(pm)) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    genes.resize(n);
+    struct SegH { int rep, gene, off; size_t rowmap_off; };
+    std::vector<SegH> segs; std::vector<int> rowmaps;
+    int max_npat = 0;
+    for (int r = 0; r < n; ++r) {
+        Gene &G = genes[r]; EncodedAlignment &A = G.aln;
+        std::vector<std::string> names;
+        for (int g : sel[r]) {
+            if (g < 0 || g >= (int)store.items.size()) return ctx->fail(-1, "gene index out of range");
+            names.insert(names.end(), store.items[g].aln.names.begin(), store.items[g].aln.names.end());
+        }
+        std::sort(names.begin(), names.end()); names.erase(std::unique(names.begin(), names.end()), names.end());   // MSAConcatenator.java:78-189: sorted union
+        const int nt = (int)names.size();
+        if (nt < 3) return ctx->fail(-2, "replicate " + std::to_string(r) + ": fewer than 3 taxa");
+        A.ntax = nt; A.names = names; A.nsites = 0; A.npat = 0;
+        std::vector<int64_t> cmp((size_t)nt * nt, 0), diff((size_t)nt * nt, 0);
+        for (int g : sel[r]) {
+            const GeneStore::Item &it = store.items[g];
+            std::vector<int> local(it.aln.ntax);                 // gene row -> replicate row
+            SegH sh{r, g, A.npat, rowmaps.size()};
+            rowmaps.resize(rowmaps.size() + nt, -1);
+            for (int i = 0; i < it.aln.ntax; ++i) {
+                local[i] = (int)(std::lower_bound(names.begin(), names.end(), it.aln.names[i]) - names.begin());
+                rowmaps[sh.rowmap_off + local[i]] = i;
+            }
+            for (int i = 0; i < it.aln.ntax; ++i) for (int j = 0; j < it.aln.ntax; ++j) {
+                cmp[(size_t)local[i] * nt + local[j]] += it.cmp[(size_t)i * it.aln.ntax + j]; diff[(size_t)local[i] * nt + local[j]] += it.diff[(size_t)i * it.aln.ntax + j];
+            }
+            segs.push_back(sh);
+            A.npat += it.aln.npat; A.nsites += it.aln.nsites; max_npat = std::max(max_npat, it.aln.npat);
+        }
+        A.mpad = (A.npat + 31) / 32 * 32;
+        G.tree = nj_from_counts(nt, cmp, diff);
+    }
+    if (int rc = layout(alpha, false)) return rc;
+    // padding patterns: gap code, weight 0; then one gather launch fills every replicate
+    for (auto &G : genes) {
+        HIPCHK(hipMemsetAsync(G.d_codes, NCODES - 1, (size_t)G.aln.ntax * G.aln.mpad, ctx->stream));
+        HIPCHK(hipMemsetAsync(G.d_weight, 0, (size_t)G.aln.mpad * 8, ctx->stream));
+    }
+    std::vector<GatherSeg> hs(segs.size());
+    void *d_buf = nullptr;
+    const size_t seg_bytes = align_up(hs.size() * sizeof(GatherSeg), 256), map_bytes = rowmaps.size() * sizeof(int);
+    HIPCHK(hipMalloc(&d_buf, seg_bytes + map_bytes));
+    const int *d_maps = (const int *)((char *)d_buf + seg_bytes);
+    for (size_t i = 0; i < segs.size(); ++i) {
+        const GeneStore::Item &it = store.items[segs[i].gene]; Gene &G = genes[segs[i].rep];
+        hs[i] = GatherSeg{it.d_codes, it.d_w, G.d_codes, G.d_weight, d_maps + segs[i].rowmap_off, it.aln.mpad, it.aln.npat, G.aln.mpad, segs[i].off, G.aln.ntax, 0};
+    }
+    hipError_t e1 = hipMemcpyAsync(d_buf, hs.data(), hs.size() * sizeof(GatherSeg), hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e2 = hipMemcpyAsync((char *)d_buf + seg_bytes, rowmaps.data(), map_bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e1 == hipSuccess && e2 == hipSuccess) launch_gather((const GatherSeg *)d_buf, (int)hs.size(), max_npat, ctx->stream);
+    hipError_t e3 = hipStreamSynchronize(ctx->stream);
+    hipFree(d_buf);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return ctx->fail(-4, "replicate gather failed");
+    return 0;
 }
 
 int Batch::chain_sync() {
@@ -656,6 +766,7 @@ int Batch::score(const std::vector<char> &active, double *lnl) {
 }
 int Batch::site_lnl(int g, double *out) {
     Gene &G = genes[g];
+    if ((int)G.aln.site2pat.size() != G.aln.nsites) return ctx->fail(-1, "per-site lnL is not available for device-gathered replicates");
     std::vector<char> act(genes.size(), 0); act[g] = 1;
     std::vector<double> l(genes.size());
     if (int rc = evaluate(act, l.data())) return rc;

@@ -68,6 +68,14 @@ struct Gene {
 
 struct pml_alignment_view { int ntax, nsites; const char *const *names; const char *const *rows; };
 
+// gene alignments encoded ONCE and kept in HBM; replicates (gene subsets) are gathered from them on the device
+struct GeneStore {
+    struct Item { EncodedAlignment aln; std::vector<int64_t> cmp, diff; uint8_t *d_codes = nullptr; double *d_w = nullptr; };
+    Ctx *ctx = nullptr; std::vector<Item> items; char *arena = nullptr;
+    int create(Ctx *c, int n, const pml_alignment_view *alns);
+    void destroy();
+};
+
 constexpr int NSCRATCH = 8;          // extra CLV slots per gene for candidate evaluation (NNI / SPR)
 enum { SIDE_TIP = 0, SIDE_MSG = 1, SIDE_SCRATCH = 2, SIDE_CHERRY = 3, SIDE_PITCH = 4 };
 // tip node id | directed-edge index (v-ntax)*3+k | scratch slot | directed-edge index of a message whose
@@ -113,6 +121,11 @@ struct Batch {
 
     int create(Ctx *c, int n, const pml_alignment_view *alns, const char *const *newicks,
                int pi_mode, int ncat, double alpha, bool score_only);
+    // one batch gene per replicate = the concatenation of the selected store genes (sorted taxon union, absent
+    // taxa = gap rows, MSAConcatenator rules); code matrices are gathered on the device, NJ start trees come from
+    // the summed pair counts: no column text is touched again
+    int create_replicates(Ctx *c, const GeneStore &store, const std::vector<std::vector<int>> &sel, int pi_mode, int ncat, double alpha);
+    int layout(double alpha, bool score_only);
     void destroy();
 
     void set_alpha(int g, double alpha);

@@ -520,21 +520,36 @@ bool tree_displays(const Tree &t, const std::vector<Constraint> &cs) {
     return true;
 }
 
-Tree nj_tree(const EncodedAlignment &a, const std::vector<Constraint> *cons) {
-    const int n = a.ntax, N = 2 * n - 2, mp = a.mpad;
-    std::vector<double> D((size_t)N * N, 0.0);
+// comparable / differing column counts of every taxon pair (integer weights: exact, so the counts of a
+// concatenation are the sums of its genes' counts -- the replicate path never touches the columns again)
+void pair_counts(const EncodedAlignment &a, std::vector<int64_t> &cmp, std::vector<int64_t> &diff) {
+    const int n = a.ntax, mp = a.mpad;
+    cmp.assign((size_t)n * n, 0); diff.assign((size_t)n * n, 0);
     std::vector<int32_t> w(a.npat);
     for (int p = 0; p < a.npat; ++p) w[p] = (int32_t)a.weight[p];
     for (int i = 0; i < n; ++i)
         for (int j = i + 1; j < n; ++j) {
-            // branch-free integer counts (auto-vectorised); sums of integer weights are exact
+            // branch-free integer counts (auto-vectorised)
             int64_t icmp = 0, idiff = 0;
             const uint8_t *ci = &a.codes[(size_t)i * mp], *cj = &a.codes[(size_t)j * mp];
             for (int p = 0; p < a.npat; ++p) {
                 const int32_t ok = (ci[p] < 20) & (cj[p] < 20);
                 icmp += ok * w[p]; idiff += (ok & (ci[p] != cj[p])) * w[p];
             }
-            const double cmp = (double)icmp, diff = (double)idiff;
+            cmp[(size_t)i * n + j] = cmp[(size_t)j * n + i] = icmp; diff[(size_t)i * n + j] = diff[(size_t)j * n + i] = idiff;
+        }
+}
+Tree nj_tree(const EncodedAlignment &a, const std::vector<Constraint> *cons) {
+    std::vector<int64_t> cmp, diff;
+    pair_counts(a, cmp, diff);
+    return nj_from_counts(a.ntax, cmp, diff, cons);
+}
+Tree nj_from_counts(int n, const std::vector<int64_t> &cmpc, const std::vector<int64_t> &diffc, const std::vector<Constraint> *cons) {
+    const int N = 2 * n - 2;
+    std::vector<double> D((size_t)N * N, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j) {
+            const double cmp = (double)cmpc[(size_t)i * n + j], diff = (double)diffc[(size_t)i * n + j];
             double d = 3.0;
             if (cmp > 0) { const double pd = diff / cmp; d = -std::log(std::max(1.0 - pd - 0.2 * pd * pd, 0.05)); }
             D[(size_t)i * N + j] = D[(size_t)j * N + i] = d;

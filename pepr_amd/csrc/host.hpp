@@ -75,6 +75,10 @@ bool tree_displays(const Tree &t, const std::vector<Constraint> &cs);
 
 // NJ start tree; with constraints only joins whose cluster is compatible with every split are made
 Tree nj_tree(const EncodedAlignment &a, const std::vector<Constraint> *cons = nullptr);
+// the two halves of nj_tree: exact integer pair counts ([n*n]: comparable columns, differing columns), and
+// Kimura distances + neighbour joining from such counts
+void pair_counts(const EncodedAlignment &a, std::vector<int64_t> &cmp, std::vector<int64_t> &diff);
+Tree nj_from_counts(int n, const std::vector<int64_t> &cmp, const std::vector<int64_t> &diff, const std::vector<Constraint> *cons = nullptr);
 
 // resumable Brent minimiser on a fixed interval (same control flow as the oracle's eng_opt_alpha)
 struct Brent {

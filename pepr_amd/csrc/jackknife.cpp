@@ -2,8 +2,8 @@
 // (PhylogenomicPipeline2.java:994-1126, 1227-1275, 1587-1633) as one native call.
 // Concatenation follows MSAConcatenator.concatenate (MSAConcatenator.java:78-189): taxa = sorted
 // union of the genes' taxon names, a gene that lacks a taxon contributes '?' columns.
-// Replicates are built in memory (no FASTA files, no per-replicate text parsing) and searched as
-// ONE device batch; the support counting is TreeSupportDecorator.addSupportValues (:86-163).
+// Gene alignments are encoded once into HBM; the full alignment and every replicate are gathered from them on
+// the device (GeneStore / Batch::create_replicates) and the replicates are searched as ONE batch; the support counting is TreeSupportDecorator.addSupportValues (:86-163).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -75,46 +75,39 @@ extern "C" int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *gene
     if (reps < 0) return PML_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->c.mu);
     try {
-        std::string err;
         std::vector<int> all(ngenes); for (int i = 0; i < ngenes; ++i) all[i] = i;
-        Concat full;
-        if (!concatenate(ngenes, genes, all, full, err)) return ctx->c.fail(PML_EINVAL, err);
+        for (int g = 0; g < ngenes; ++g) if (!genes[g].names || !genes[g].rows || genes[g].ntax <= 0) return ctx->c.fail(PML_EINVAL, "bad alignment");
+        // every gene is encoded once and stays in HBM; the full alignment and each replicate are index lists over
+        // that store, materialised by k_gather -- no concatenated text, no per-replicate encode
+        GeneStore store;
+        struct Drop { GeneStore &s; ~Drop() { s.destroy(); } } drop{store};
+        static_assert(sizeof(pml_alignment) == sizeof(pml_alignment_view), "alignment view layout");
+        if (int rc = store.create(&ctx->c, ngenes, reinterpret_cast<const pml_alignment_view *>(genes))) return rc;
         // replicates: seeded draw without replacement (reference: RandomSetUtils.getRandomSet, unseeded)
         std::mt19937_64 rng(opts ? opts->seed : 0);
-        std::vector<Concat> rep((size_t)reps);
+        std::vector<std::vector<int>> rep((size_t)reps);
         for (int r = 0; r < reps; ++r) {
             std::vector<int> pool(all);
             for (int i = 0; i < subset; ++i) { const size_t j = i + (size_t)(rng() % (uint64_t)(ngenes - i)); std::swap(pool[i], pool[j]); }
-            std::vector<int> sel(pool.begin(), pool.begin() + subset);
-            std::sort(sel.begin(), sel.end());
-            if (!concatenate(ngenes, genes, sel, rep[r], err)) return ctx->c.fail(PML_EINVAL, err);
+            rep[r].assign(pool.begin(), pool.begin() + subset);
+            std::sort(rep[r].begin(), rep[r].end());
         }
-        auto view = [](const Concat &c, std::vector<const char *> &np, std::vector<const char *> &rp) {
-            np.clear(); rp.clear();
-            for (auto &s : c.names) np.push_back(s.c_str());
-            for (auto &s : c.rows) rp.push_back(s.c_str());
-            return pml_alignment_view{(int)c.names.size(), (int)c.rows[0].size(), np.data(), rp.data()};
-        };
         const int ncat = model ? model->ncat : 4, pm = model ? model->pi_mode : 0;
         const double alpha = model ? model->alpha : 1.0;
         // full tree
-        Tree main_tree; std::vector<std::string> main_names; double main_lnl = 0, main_alpha = alpha; int main_npat = 0;
+        Tree main_tree; std::vector<std::string> main_names; double main_lnl = 0, main_alpha = alpha; int main_npat = 0, main_nsites = 0;
         {
-            std::vector<const char *> np, rp; pml_alignment_view v = view(full, np, rp);
-            Batch b; int rc = b.create(&ctx->c, 1, &v, nullptr, pm, ncat, alpha, false);
+            Batch b; int rc = b.create_replicates(&ctx->c, store, {all}, pm, ncat, alpha);
             if (!rc) rc = b.search(true, spr_full, true, eps, &main_lnl);
             if (rc) { b.destroy(); return rc; }
-            main_tree = b.genes[0].tree; main_names = b.genes[0].aln.names; main_alpha = b.genes[0].alpha; main_npat = b.genes[0].aln.npat;
+            main_tree = b.genes[0].tree; main_names = b.genes[0].aln.names; main_alpha = b.genes[0].alpha; main_npat = b.genes[0].aln.npat; main_nsites = b.genes[0].aln.nsites;
             b.destroy();
         }
         // support trees: one batch
         std::vector<Tree> sup((size_t)reps);
         std::string sup_txt;
         if (reps > 0) {
-            std::vector<std::vector<const char *>> nps(reps), rps(reps);
-            std::vector<pml_alignment_view> vs(reps);
-            for (int r = 0; r < reps; ++r) vs[r] = view(rep[r], nps[r], rps[r]);
-            Batch b; int rc = b.create(&ctx->c, reps, vs.data(), nullptr, pm, ncat, alpha, false);
+            Batch b; int rc = b.create_replicates(&ctx->c, store, rep, pm, ncat, alpha);
             std::vector<double> l(reps);
             if (!rc) rc = b.search(true, 0, true, eps, l.data());
             if (rc) { b.destroy(); return rc; }
@@ -133,7 +126,7 @@ extern "C" int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *gene
         for (auto &t : sup) if (t.ntax == main_tree.ntax) usable.push_back(t);
         const std::string out = main_tree.newick_labeled(main_names, 6, support_counts(main_tree, usable));
         main_out->lnl = main_lnl; main_out->alpha = main_alpha; main_out->tree_length = main_tree.length();
-        main_out->npatterns = main_npat; main_out->nsites = (int)full.rows[0].size();
+        main_out->npatterns = main_npat; main_out->nsites = main_nsites;
         main_out->newick = dup_cstr(out);
         if (support_out) *support_out = dup_cstr(sup_txt);
         if (!main_out->newick) return ctx->c.fail(PML_ENOMEM, "host allocation failed");

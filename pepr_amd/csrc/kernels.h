@@ -101,6 +101,14 @@ constexpr int NEWTON_SYNC_DOUBLES = 2 + 2 * NEWTON_MAX_SPLIT * 3 + 14;   // 64 d
 
 enum { MODE_NEWVIEW = 0, MODE_SUMTABLE = 1, MODE_EVALUATE = 2 };
 
+// one gene's patterns copied into a replicate (jackknife concatenation on the device):
+// dst[t][dst_off + p] = rowmap[t] >= 0 ? src[rowmap[t]][p] : gap code, dst_w[dst_off + p] = w[p]
+struct GatherSeg {
+    const uint8_t *src; const double *w; uint8_t *dst; double *dst_w; const int *rowmap;
+    int src_mpad, npat, dst_mpad, dst_off, ntax_dst, pad;
+};
+void launch_gather(const GatherSeg *segs, int nsegs, int max_npat, hipStream_t s);
+
 void launch_pmat(const ModelDev *model, const PmatReq *reqs, double *frags, int n, hipStream_t s);
 // constant fragment sets for the eigen-basis transforms used by the sumtable:
 //   set 0: x_i = sum_s pi_s U[s][i] A[s]     set 1: y_i = sum_j Uinv[i][j] B[j]

@@ -609,8 +609,27 @@ __global__ __launch_bounds__(256, 3) void k_newton(const ModelDev *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// k_gather: build a replicate's code matrix from gene matrices already resident in HBM (byte copies,
+// HBM-bound; one thread per pattern, rows walked in a loop so stores of a wavefront are contiguous)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather(const GatherSeg *__restrict__ segs) {
+    const GatherSeg g = segs[blockIdx.x];
+    const int p = blockIdx.y * 256 + threadIdx.x;
+    if (p >= g.npat) return;
+    g.dst_w[g.dst_off + p] = g.w[p];
+    for (int t = 0; t < g.ntax_dst; ++t) {
+        const int row = g.rowmap[t];
+        g.dst[(size_t)t * g.dst_mpad + g.dst_off + p] = row >= 0 ? g.src[(size_t)row * g.src_mpad + p] : (uint8_t)(NCODES - 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+void launch_gather(const GatherSeg *segs, int nsegs, int max_npat, hipStream_t s) {
+    if (nsegs <= 0 || max_npat <= 0) return;
+    hipLaunchKernelGGL(k_gather, dim3((unsigned)nsegs, (unsigned)((max_npat + 255) / 256)), dim3(256), 0, s, segs);
+}
 void launch_pmat(const ModelDev *model, const PmatReq *reqs, double *frags, int n, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_pmat, dim3(n), dim3(256), 0, s, model, reqs, frags, n);
