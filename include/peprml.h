@@ -166,6 +166,11 @@ typedef struct {
     unsigned long long seed;
     int spr_radius_full;         /* SPR radius for the full tree (0 = NNI only) */
     double epsilon;              /* search epsilon (0 = 1e-3) */
+    /* multi-GPU: every rank passes the same genes/seed; this call searches only replicates r with
+     * r % shard_world == shard_rank and the full tree only on shard_rank 0 (elsewhere main_out->newick is
+     * NULL and carries no supports); the caller gathers the support trees and decorates with
+     * pml_support_tree (pepr_amd/distributed.py: jackknife()).  0,0 or world <= 1 = everything here. */
+    int shard_rank, shard_world;
 } pml_jackknife_opts;
 int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *genes, const pml_model *model,
                   const pml_jackknife_opts *opts, pml_result *main_out /* newick carries the supports */,

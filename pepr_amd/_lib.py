@@ -43,7 +43,8 @@ class SearchOpts(C.Structure):
 
 class JackknifeOpts(C.Structure):
     _fields_ = [("reps", C.c_int), ("subset_size", C.c_int), ("seed", C.c_ulonglong),
-                ("spr_radius_full", C.c_int), ("epsilon", C.c_double)]
+                ("spr_radius_full", C.c_int), ("epsilon", C.c_double),
+                ("shard_rank", C.c_int), ("shard_world", C.c_int)]
 
 
 class ParsimonyOpts(C.Structure):

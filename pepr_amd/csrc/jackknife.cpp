@@ -73,6 +73,8 @@ extern "C" int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *gene
     const double eps = (opts && opts->epsilon > 0) ? opts->epsilon : 1e-3;
     const int spr_full = opts ? opts->spr_radius_full : 5;
     if (reps < 0) return PML_EINVAL;
+    const int sworld = (opts && opts->shard_world > 1) ? opts->shard_world : 1, srank = sworld > 1 ? opts->shard_rank : 0;
+    if (srank < 0 || srank >= sworld) return PML_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->c.mu);
     try {
         std::vector<int> all(ngenes); for (int i = 0; i < ngenes; ++i) all[i] = i;
@@ -92,11 +94,17 @@ extern "C" int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *gene
             rep[r].assign(pool.begin(), pool.begin() + subset);
             std::sort(rep[r].begin(), rep[r].end());
         }
+        if (sworld > 1) {                       // this rank's replicates (all ranks drew the same lists)
+            std::vector<std::vector<int>> mine;
+            for (int r = srank; r < reps; r += sworld) mine.push_back(rep[r]);
+            rep.swap(mine);
+        }
+        const int reps_here = (int)rep.size();
         const int ncat = model ? model->ncat : 4, pm = model ? model->pi_mode : 0;
         const double alpha = model ? model->alpha : 1.0;
         // full tree
         Tree main_tree; std::vector<std::string> main_names; double main_lnl = 0, main_alpha = alpha; int main_npat = 0, main_nsites = 0;
-        {
+        if (srank == 0) {
             Batch b; int rc = b.create_replicates(&ctx->c, store, {all}, pm, ncat, alpha);
             if (!rc) rc = b.search(true, spr_full, true, eps, &main_lnl);
             if (rc) { b.destroy(); return rc; }
@@ -104,19 +112,20 @@ extern "C" int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *gene
             b.destroy();
         }
         // support trees: one batch
-        std::vector<Tree> sup((size_t)reps);
+        std::vector<Tree> sup((size_t)reps_here);
         std::string sup_txt;
-        if (reps > 0) {
+        if (reps_here > 0) {
             Batch b; int rc = b.create_replicates(&ctx->c, store, rep, pm, ncat, alpha);
-            std::vector<double> l(reps);
+            std::vector<double> l(reps_here);
             if (!rc) rc = b.search(true, 0, true, eps, l.data());
             if (rc) { b.destroy(); return rc; }
-            for (int r = 0; r < reps; ++r) {
+            for (int r = 0; r < reps_here; ++r) {
                 const Gene &G = b.genes[r];
                 const std::string nw = G.tree.newick(G.aln.names, 6);
                 sup_txt += nw; sup_txt += '\n';
                 // a replicate may lack taxa that occur only in unselected genes: such trees cannot
                 // contain the main tree's bipartitions and are counted as not supporting
+                if (srank != 0) continue;
                 if (G.aln.names == main_names) sup[r] = G.tree;
                 else { std::string e2; Tree t; if (Tree::parse(nw.c_str(), main_names, t, e2)) sup[r] = t; else sup[r] = Tree(); }
             }
@@ -124,12 +133,12 @@ extern "C" int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *gene
         }
         std::vector<Tree> usable;
         for (auto &t : sup) if (t.ntax == main_tree.ntax) usable.push_back(t);
-        const std::string out = main_tree.newick_labeled(main_names, 6, support_counts(main_tree, usable));
+        const std::string out = srank == 0 ? main_tree.newick_labeled(main_names, 6, support_counts(main_tree, usable)) : std::string();
         main_out->lnl = main_lnl; main_out->alpha = main_alpha; main_out->tree_length = main_tree.length();
         main_out->npatterns = main_npat; main_out->nsites = main_nsites;
-        main_out->newick = dup_cstr(out);
+        if (srank == 0) main_out->newick = dup_cstr(out);
         if (support_out) *support_out = dup_cstr(sup_txt);
-        if (!main_out->newick) return ctx->c.fail(PML_ENOMEM, "host allocation failed");
+        if (srank == 0 && !main_out->newick) return ctx->c.fail(PML_ENOMEM, "host allocation failed");
     } catch (const std::bad_alloc &) { return ctx->c.fail(PML_ENOMEM, "host allocation failed"); }
     catch (const std::exception &e) { return ctx->c.fail(PML_EINVAL, e.what()); }
     return PML_OK;

@@ -76,3 +76,33 @@ def gather_results(gene_ids, lnl, alpha=None, tree_length=None, newicks=None, ne
                 d["newick"] = row[RECORD_HEADER:].copy().view(np.uint8).tobytes().split(b"\0", 1)[0].decode()
             out[gid] = d
     return out
+
+
+def jackknife(ctx, genes, reps=100, seed=0, newick_bytes=0, **kw):
+    """Gene-wise jackknife over all ranks (PhylogenomicPipeline2.java:994-1126 across GPUs): rank r searches the
+    replicates r, r+world, ... (pml_jackknife_opts.shard_*; every rank draws the same subsets from `seed`), rank 0
+    also searches the full tree; ONE gather of the support trees, then the supports are counted on rank 0.
+    Returns the single-GPU result dict on rank 0, None elsewhere."""
+    from . import engine
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    part = ctx.jackknife(genes, reps=reps, seed=seed, shard=(rank, world), **kw)
+    if world == 1:
+        return part
+    mine = part["support_trees"]
+    per = (reps + world - 1) // world
+    if not newick_bytes:
+        ntax = len({t for g in genes for t in g[0]})
+        newick_bytes = 64 * ntax + 64
+    ids = [rank + world * i if i < len(mine) else -1 for i in range(per)]
+    recs = gather_results(ids, np.zeros(per), newicks=mine + [""] * (per - len(mine)), newick_bytes=newick_bytes)
+    if rank != 0:
+        return None
+    sup = [recs[i]["newick"] for i in sorted(recs)]
+    import re
+    plain = re.sub(r"\)\d+:", "):", part["newick"])
+    part["support_trees"] = sup
+    leaves = lambda t: sorted(re.findall(r"[(,]([^(),:;]+)", t))
+    # a replicate that lacks taxa of the full tree cannot contain its bipartitions (counted as not supporting)
+    part["newick"] = engine.support_tree(plain, [t for t in sup if t and leaves(t) == leaves(plain)], digits=6)
+    return part

@@ -186,20 +186,20 @@ class Context:
         return out
 
     def jackknife(self, genes, reps=100, subset_size=0, seed=0, spr_radius_full=5, epsilon=1e-3, alpha=1.0,
-                  ncat=4, pi_mode=PI_RAXML_3DP):
+                  ncat=4, pi_mode=PI_RAXML_3DP, shard=(0, 1)):
         """Full tree + `reps` gene-subset support trees + support counts (PhylogenomicPipeline2.java:994-1126).
         genes: list of (names, rows), possibly over different taxon subsets."""
         keep = []
         n = len(genes)
         alns = (_lib.Alignment * n)(*[_aln_struct(g[0], g[1], keep) for g in genes])
-        o = _lib.JackknifeOpts(reps, subset_size, seed, spr_radius_full, epsilon)
+        o = _lib.JackknifeOpts(reps, subset_size, seed, spr_radius_full, epsilon, int(shard[0]), int(shard[1]))
         m = _model(ncat, alpha, pi_mode)
         res = _lib.Result()
         sup = C.c_void_p()
         rc = self.L.pml_jackknife(self.ptr, n, alns, C.byref(m), C.byref(o), C.byref(res), C.byref(sup))
         self._check(rc)
         out = {"lnl": res.lnl, "alpha": res.alpha, "tree_length": res.tree_length, "npatterns": res.npatterns,
-               "nsites": res.nsites, "newick": C.string_at(res.newick).decode(),
+               "nsites": res.nsites, "newick": C.string_at(res.newick).decode() if res.newick else None,
                "support_trees": C.string_at(sup).decode().splitlines() if sup else []}
         self.L.pml_result_free(C.byref(res))
         if sup:

@@ -53,3 +53,23 @@ def test_jackknife_all_genes_gives_full_support(gpu_ctx):
     sup = [int(x) for x in re.findall(r"\)(\d+):", r["newick"])]
     assert sup == [6] * (8 - 3)
     assert len(set(r["support_trees"])) == 1
+
+
+def test_jackknife_sharded_equals_unsharded(gpu_ctx):
+    """pml_jackknife_opts.shard_*: the multi-GPU split of the replicates (one rank per GPU) reproduces the
+    single-GPU call: same replicate trees in rank-interleaved order, same supports after decoration."""
+    import re
+    names, true_nw, genes = _genes(9, 8, 100, 11, drop=1)
+    whole = gpu_ctx.jackknife(genes, reps=7, seed=3, spr_radius_full=5)
+    parts = [gpu_ctx.jackknife(genes, reps=7, seed=3, spr_radius_full=5, shard=(r, 3)) for r in range(3)]
+    assert parts[1]["newick"] is None and parts[2]["newick"] is None
+    assert [len(p["support_trees"]) for p in parts] == [3, 2, 2]
+    merged = [None] * 7
+    for r, p in enumerate(parts):
+        for i, t in enumerate(p["support_trees"]):
+            merged[r + 3 * i] = t
+    assert merged == whole["support_trees"]
+    plain = re.sub(r"\)\d+:", "):", parts[0]["newick"])
+    decorated = engine.support_tree(plain, merged, digits=6)
+    assert sorted(re.findall(r"\)(\d+):", decorated)) == sorted(re.findall(r"\)(\d+):", whole["newick"]))
+    assert engine.rf_distance(decorated, whole["newick"]) == 0
