@@ -29,7 +29,8 @@
  * Conventions: caller owns inputs (nothing is retained after return);
  * the library allocates results, the caller releases them with pml_result_free(); no files, no
  * cwd dependence, no stdout/stderr output; every function returns 0 or a negative PML_E* code and
- * never aborts or throws.  A context may be used from several threads: calls serialise on it.
+ * never aborts or throws.  A context may be used from several threads: batch calls serialise on it,
+ * concurrent single-gene calls are coalesced into one device batch (pml_coalescing_stats).
  * The alignment rows are exactly SequenceAlignment.alignedSequenceChars
  * (.../pepr/alignment/SequenceAlignment.java:61): one char row per taxon, 20 amino-acid letters,
  * '-' gap, '?' absent gene, anything else unknown (treated like a gap; B/Z are N|D and Q|E).
@@ -198,6 +199,10 @@ int pml_bootstrap(pml_ctx *ctx, const pml_alignment *aln, const pml_model *model
 /* host-only: FASTA text (">taxon\nSEQ\n" per taxon, SequenceAlignment.java:405-416) of the
  * concatenation of the selected genes (sel == NULL: all), taxa = sorted union, '?' padding */
 int pml_concatenate(int ngenes, const pml_alignment *genes, int nsel, const int *sel, char **fasta_out);
+
+/* Concurrent pml_score / pml_optimize / pml_search calls on one context (PEPR's tree_threads workers) are
+ * coalesced into device batches; this reports how many batches ran and how many single calls they carried. */
+int pml_coalescing_stats(pml_ctx *ctx, long long *batches, long long *requests);
 
 /* profiling: HIP-event time of device kernels since the last reset (cfg.profile = 1) */
 enum { PML_K_PMAT = 0, PML_K_NEWVIEW = 1, PML_K_EVALUATE = 2, PML_K_SUMTABLE = 3, PML_K_NEWTON = 4,

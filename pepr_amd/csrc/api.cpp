@@ -239,16 +239,95 @@ static int oneshot(pml_ctx *ctx, int op, int n, const pml_alignment *alns, const
     return rc;
 }
 
+}  // extern "C"
+
+// ---- coalescing of concurrent single-gene calls ---------------------------------------------
+// PEPR calls the tree builder from up to `tree_threads` Java threads at once (PhylogenomicPipeline2.java:
+// 1039-1054, 1233-1254), each blocking on ONE alignment.  A single small gene cannot fill 256 CUs, so instead of
+// serialising such calls the first caller that finds no batch in flight becomes the leader: it takes every queued
+// request with the same operation / model / options, runs them as one device batch and wakes their owners.
+// Requests that arrive meanwhile form the next batch.  Blocking semantics and results are those of the
+// single call (batches are bit-reproducible whatever their composition).
+struct pml_request {
+    int op, flags; const pml_alignment *aln; const char *nw;
+    pml_model model; pml_search_opts opts; pml_result *out;
+    int rc = 0; bool done = false; std::string err;
+};
+static bool compatible(const pml_request &a, const pml_request &b) {
+    return a.op == b.op && a.flags == b.flags && a.model.ncat == b.model.ncat && a.model.alpha == b.model.alpha &&
+           a.model.pi_mode == b.model.pi_mode && a.opts.optimize_alpha == b.opts.optimize_alpha && a.opts.nni == b.opts.nni &&
+           a.opts.spr_radius == b.opts.spr_radius && a.opts.epsilon == b.opts.epsilon;
+}
+static void run_group(pml_ctx *ctx, std::vector<pml_request *> &grp) {
+    const int n = (int)grp.size();
+    std::vector<pml_alignment> alns(n); std::vector<const char *> nws(n); std::vector<pml_result> res(n);
+    bool any_nw = false;
+    for (int i = 0; i < n; ++i) { alns[i] = *grp[i]->aln; nws[i] = grp[i]->nw; any_nw |= grp[i]->nw != nullptr; }
+    pml_request &f = *grp[0];
+    int rc = oneshot(ctx, f.op, n, alns.data(), any_nw ? nws.data() : nullptr, &f.model, &f.opts, f.flags, res.data());
+    if (rc && n > 1) {                      // one bad input must not fail its neighbours: redo one by one
+        for (int i = 0; i < n; ++i) {
+            pml_result_free(&res[i]);
+            grp[i]->rc = oneshot(ctx, f.op, 1, &alns[i], nws[i] ? &nws[i] : nullptr, &f.model, &f.opts, f.flags, grp[i]->out);
+            if (grp[i]->rc) { std::lock_guard<std::mutex> g(ctx->c.mu); grp[i]->err = ctx->c.last_error; }
+        }
+        return;
+    }
+    std::string err;
+    if (rc) { std::lock_guard<std::mutex> g(ctx->c.mu); err = ctx->c.last_error; }
+    for (int i = 0; i < n; ++i) { *grp[i]->out = res[i]; grp[i]->rc = rc; grp[i]->err = err; }
+}
+static int single(pml_ctx *ctx, int op, const pml_alignment *aln, const char *nw, const pml_model *model,
+                  const pml_search_opts *opts, int flags, pml_result *out) {
+    if (!ctx || !aln || !out) return PML_EINVAL;
+    if (op != OP_SEARCH && !nw) { std::memset(out, 0, sizeof *out); return ctx->c.fail(PML_EINVAL, "newick required"); }
+    if (opts && opts->nconstraints > 0) return oneshot(ctx, op, 1, aln, nw ? &nw : nullptr, model, opts, flags, out);   // caller-owned matrix: alone
+    pml_request r;
+    r.op = op; r.flags = flags; r.aln = aln; r.nw = nw; r.out = out;
+    r.model = model ? *model : pml_model{4, 1.0, PML_PI_RAXML_3DP};
+    if (opts) r.opts = *opts;
+    else { std::memset(&r.opts, 0, sizeof r.opts); r.opts.optimize_alpha = 1; r.opts.nni = 1; }   // epsilon 0 = the operation's default
+    r.opts.nconstraints = 0; r.opts.constraint_ntax = 0; r.opts.constraint_names = nullptr; r.opts.constraint_rows = nullptr;
+    std::unique_lock<std::mutex> lk(ctx->qmu);
+    ctx->queue.push_back(&r);
+    while (!r.done) {
+        if (ctx->leader) { ctx->qcv.wait(lk); continue; }
+        ctx->leader = true;
+        std::vector<pml_request *> grp, rest;
+        for (pml_request *q : ctx->queue) (compatible(*ctx->queue.front(), *q) ? grp : rest).push_back(q);
+        ctx->queue.swap(rest);
+        ctx->coalesced_batches++; ctx->coalesced_requests += (long long)grp.size();
+        lk.unlock();
+        try { run_group(ctx, grp); }
+        catch (...) { for (pml_request *q : grp) { q->rc = PML_ENOMEM; q->err = "host allocation failed"; } }
+        lk.lock();
+        for (pml_request *q : grp) q->done = true;
+        ctx->leader = false;
+        ctx->qcv.notify_all();
+    }
+    if (r.rc) { std::lock_guard<std::mutex> g(ctx->c.mu); ctx->c.last_error = r.err; }
+    return r.rc;
+}
+
+extern "C" {
+
+int pml_coalescing_stats(pml_ctx *ctx, long long *batches, long long *requests) {
+    if (!ctx) return PML_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->qmu);
+    if (batches) *batches = ctx->coalesced_batches;
+    if (requests) *requests = ctx->coalesced_requests;
+    return PML_OK;
+}
 int pml_score(pml_ctx *ctx, const pml_alignment *aln, const char *newick, const pml_model *model, int flags, pml_result *out) {
-    return oneshot(ctx, OP_SCORE, 1, aln, &newick, model, nullptr, flags, out);
+    return single(ctx, OP_SCORE, aln, newick, model, nullptr, flags, out);
 }
 int pml_optimize(pml_ctx *ctx, const pml_alignment *aln, const char *newick, const pml_model *model,
                  const pml_search_opts *opts, pml_result *out) {
-    return oneshot(ctx, OP_OPTIMIZE, 1, aln, &newick, model, opts, 0, out);
+    return single(ctx, OP_OPTIMIZE, aln, newick, model, opts, 0, out);
 }
 int pml_search(pml_ctx *ctx, const pml_alignment *aln, const char *start, const pml_model *model,
                const pml_search_opts *opts, pml_result *out) {
-    return oneshot(ctx, OP_SEARCH, 1, aln, start ? &start : nullptr, model, opts, 0, out);
+    return single(ctx, OP_SEARCH, aln, start, model, opts, 0, out);
 }
 int pml_score_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks, const pml_model *model,
                     int flags, pml_result *out) {

@@ -2,5 +2,14 @@
 #pragma once
 #include "engine.hpp"
 
-struct pml_ctx { pml::Ctx c; };
+#include <condition_variable>
+
+// one queued single-gene call (pml_score / pml_optimize / pml_search): concurrent callers are coalesced into
+// ONE device batch by whichever caller finds no batch in flight (SURVEY 8b "Threading")
+struct pml_request;
+struct pml_ctx {
+    pml::Ctx c;
+    std::mutex qmu; std::condition_variable qcv; std::vector<pml_request *> queue; bool leader = false;
+    long long coalesced_batches = 0, coalesced_requests = 0;
+};
 struct pml_batch { pml::Batch b; pml_ctx *owner; };

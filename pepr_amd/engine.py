@@ -206,6 +206,37 @@ class Context:
             self.L.pml_free(sup)
         return out
 
+    # ---- single-gene calls (what one Java thread issues); concurrent ones are coalesced inside the library ----
+    def _single(self, fn, gene, newick, model, extra):
+        keep = []
+        a = _aln_struct(gene[0], gene[1], keep)
+        res = _lib.Result()
+        rc = fn(self.ptr, C.byref(a), newick.encode() if newick is not None else None, C.byref(model), *extra, C.byref(res))
+        d = None
+        if rc == 0:
+            d = {"lnl": res.lnl, "alpha": res.alpha, "tree_length": res.tree_length, "npatterns": res.npatterns,
+                 "nsites": res.nsites, "newick": C.string_at(res.newick).decode() if res.newick else None}
+        self.L.pml_result_free(C.byref(res))
+        self._check(rc)
+        return d
+
+    def score_one(self, gene, newick, alpha=1.0, ncat=4, pi_mode=PI_RAXML_3DP):
+        return self._single(self.L.pml_score, gene, newick, _model(ncat, alpha, pi_mode), (0,))
+
+    def optimize_one(self, gene, newick, alpha=1.0, ncat=4, pi_mode=PI_RAXML_3DP, optimize_alpha=True, epsilon=1e-4):
+        o = _opts(optimize_alpha, False, 0, epsilon)
+        return self._single(self.L.pml_optimize, gene, newick, _model(ncat, alpha, pi_mode), (C.byref(o),))
+
+    def search_one(self, gene, start=None, alpha=1.0, ncat=4, pi_mode=PI_RAXML_3DP, optimize_alpha=True, nni=True,
+                   spr_radius=0, epsilon=1e-3):
+        o = _opts(optimize_alpha, nni, spr_radius, epsilon)
+        return self._single(self.L.pml_search, gene, start, _model(ncat, alpha, pi_mode), (C.byref(o),))
+
+    def coalescing_stats(self):
+        b, r = C.c_longlong(), C.c_longlong()
+        self._check(self.L.pml_coalescing_stats(self.ptr, C.byref(b), C.byref(r)))
+        return {"batches": b.value, "requests": r.value}
+
     def kernel_stats(self, reset=False):
         out = {}
         for name, k in KERNELS.items():

@@ -319,6 +319,39 @@ def test_thread_safety_and_two_contexts(gpu_ctx):
 
 
 
+def test_concurrent_single_calls_are_coalesced(gpu_ctx):
+    """8 threads, each blocking on ONE tree build like PEPR's GeneSubsetTreeRunnable workers
+    (PhylogenomicPipeline2.java:1587-1633): the library runs them as a few device batches; every caller gets
+    exactly the result of a lone call; a caller with bad input fails alone."""
+    import threading
+    genes = [synth.simulate_alignment(9 + i % 4, 160 + 10 * i, 740 + i) for i in range(8)]
+    alone = [gpu_ctx.search([(g[0], g[1])], None, nni=True, spr_radius=0)[0] for g in genes]
+    before = gpu_ctx.coalescing_stats()
+    out, errs = [None] * 9, [None] * 9
+    def work(i):
+        try:
+            if i == 8:
+                out[i] = gpu_ctx.search_one((genes[0][0], genes[0][1]), start="(nope:1,t1:1,t2:1);")   # parse error inside the library
+            else:
+                out[i] = gpu_ctx.search_one((genes[i][0], genes[i][1]))
+        except Exception as e:
+            errs[i] = e
+    th = [threading.Thread(target=work, args=(i,)) for i in range(9)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert errs[8] is not None and all(e is None for e in errs[:8])
+    for a, b in zip(alone, out[:8]):
+        assert a["newick"] == b["newick"] and a["lnl"] == b["lnl"] and a["alpha"] == b["alpha"]
+    st = gpu_ctx.coalescing_stats()
+    assert st["requests"] - before["requests"] >= 9
+    assert st["batches"] - before["batches"] < st["requests"] - before["requests"]      # some calls shared a batch
+    # score / optimize singles go through the same queue
+    s1 = gpu_ctx.score_one((genes[0][0], genes[0][1]), genes[0][2], alpha=0.7)
+    assert s1["lnl"] == gpu_ctx.score([(genes[0][0], genes[0][1])], [genes[0][2]], alpha=0.7)[0]["lnl"]
+    o1 = gpu_ctx.optimize_one((genes[1][0], genes[1][1]), genes[1][2])
+    assert o1["lnl"] == gpu_ctx.optimize([(genes[1][0], genes[1][1])], [genes[1][2]])[0]["lnl"]
+
+
 def test_oneshot_sub_batching(gpu_ctx, monkeypatch):
     """gene lists larger than free HBM are processed in consecutive sub-batches (config C5 scale);
     forced here with a tiny budget: results must equal the single-batch results"""
