@@ -38,6 +38,12 @@ int pml_create(const pml_config *cfg, pml_ctx **out) {
     if (!c) return PML_ENOMEM;
     const int rc = c->c.init(cfg ? cfg->device : 0, cfg ? cfg->profile != 0 : false);
     if (rc) { g_err = c->c.last_error; delete c; return rc; }
+    if (cfg && cfg->arena_bytes > 0) {
+        if (hipMalloc((void **)&c->c.arena_cache, cfg->arena_bytes) != hipSuccess) {
+            g_err = "arena_bytes does not fit on the device"; c->c.destroy(); delete c; return PML_ENOMEM;
+        }
+        c->c.arena_cache_bytes = cfg->arena_bytes;
+    }
     *out = c;
     return PML_OK;
 }
@@ -222,6 +228,7 @@ static int oneshot(pml_ctx *ctx, int op, int n, const pml_alignment *alns, const
     size_t free_b = 0, total_b = 0;
     hipSetDevice(ctx->c.device);
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)1 << 40;
+    free_b += ctx->c.arena_cache_bytes;            // the cached arena is reused or released by the next batch
     size_t budget = (size_t)(0.85 * (double)free_b);
     if (const char *e = std::getenv("PML_HBM_BUDGET_MB")) budget = (size_t)std::atoll(e) << 20;   // test hook
     int rc = 0, begin = 0;

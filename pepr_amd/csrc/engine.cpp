@@ -44,6 +44,8 @@ void Ctx::destroy() {
     for (auto e : pool) hipEventDestroy(e);
     pool.clear();
     for (int i = 0; i < 2; ++i) { if (d_model[i]) hipFree(d_model[i]); if (d_eigfrags[i]) hipFree(d_eigfrags[i]); d_model[i] = nullptr; d_eigfrags[i] = nullptr; }
+    if (arena_cache) hipFree(arena_cache);
+    arena_cache = nullptr; arena_cache_bytes = 0;
     if (stream) hipStreamDestroy(stream);
     stream = nullptr;
 }
@@ -93,6 +95,7 @@ void Ctx::resolve_events() {
 // Batch: creation / layout
 // ------------------------------------------------------------------------------------------
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static double now_ms();
 
 int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *const *newicks, int pm, int nc,
                   double alpha, bool score_only) {
@@ -104,6 +107,7 @@ int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *con
     if (int rc = ctx->ensure_model(pm)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     genes.resize(n);
+    const double t_create0 = now_ms();
     {   // encode / parse / NJ are independent per gene: host threads (plain std::thread, no GPU work)
         const int nthreads = std::max(1, std::min({n, 16, (int)std::thread::hardware_concurrency()}));
         std::vector<std::string> errs(n);
@@ -124,6 +128,7 @@ int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *con
         for (auto &t : pool) t.join();
         for (int g = 0; g < n; ++g) if (!errs[g].empty()) return ctx->fail(-2, "gene " + std::to_string(g) + ": " + errs[g]);
     }
+    if (std::getenv("PML_TRACE")) fprintf(stderr, "[pml] create: encode + start trees of %d genes %.1f ms\n", n, now_ms() - t_create0);
     return layout(alpha, score_only);
 }
 
@@ -149,9 +154,16 @@ int Batch::layout(double alpha, bool score_only) {
         total += (size_t)MAXTAIL * align_up((size_t)mp * 8, 256);      // per-pattern lnL
     }
     arena_bytes = total;
-    if (hipMalloc((void **)&arena, total) != hipSuccess) {
-        arena = nullptr;
-        return ctx->fail(-4, "device arena of " + std::to_string(total >> 20) + " MiB does not fit");
+    const double t_alloc0 = now_ms();
+    if (ctx->arena_cache && ctx->arena_cache_bytes >= total) {        // reuse: no driver allocation, no zero-fill
+        arena = ctx->arena_cache; arena_bytes = ctx->arena_cache_bytes;
+        ctx->arena_cache = nullptr; ctx->arena_cache_bytes = 0;
+    } else {
+        if (ctx->arena_cache) { hipFree(ctx->arena_cache); ctx->arena_cache = nullptr; ctx->arena_cache_bytes = 0; }
+        if (hipMalloc((void **)&arena, total) != hipSuccess) {
+            arena = nullptr;
+            return ctx->fail(-4, "device arena of " + std::to_string(total >> 20) + " MiB does not fit");
+        }
     }
     for (int g = 0; g < n; ++g) {
         Gene &G = genes[g];
@@ -175,13 +187,19 @@ int Batch::layout(double alpha, bool score_only) {
     HIPCHK(hipHostMalloc((void **)&h_scalars, sizeof(double) * 8 * MAXTAIL * n, hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void **)&d_scalars, h_scalars, 0));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (std::getenv("PML_TRACE")) fprintf(stderr, "[pml] layout: arena %.1f GiB allocated + uploaded in %.1f ms\n", (double)total / (1 << 30), now_ms() - t_alloc0);
     return 0;
 }
 
 void Batch::destroy() {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    if (arena) hipFree(arena);
+    if (arena) {
+        if (ctx->arena_cache_bytes < arena_bytes) {                  // keep the larger one for the next batch
+            if (ctx->arena_cache) hipFree(ctx->arena_cache);
+            ctx->arena_cache = arena; ctx->arena_cache_bytes = arena_bytes;
+        } else hipFree(arena);
+    }
     if (h_stage) hipHostFree(h_stage);
     if (d_stage) hipFree(d_stage);
     if (d_frags) hipFree(d_frags);

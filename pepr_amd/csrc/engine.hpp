@@ -29,6 +29,10 @@ struct Ctx {
     struct Ev { int kind; hipEvent_t a, b; };
     std::vector<Ev> pending;
     std::vector<hipEvent_t> pool;
+    // the last destroyed batch's device arena, kept for the next batch: the driver zero-fills fresh allocations at
+    // ~40 GB/s (a 111 GiB C4 arena costs 3-6 s), so back-to-back batches (full tree then replicates, successive
+    // one-shot calls) reuse it; released by destroy() or when a larger one replaces it
+    char *arena_cache = nullptr; size_t arena_cache_bytes = 0;
 
     int init(int dev, bool prof);
     void destroy();

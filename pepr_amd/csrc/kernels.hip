@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : 3) void k_oplist(
             __syncthreads();
         }
         if (active) chunk_op<PREFETCH>(op, buf, sT, p, lane);
-        if (op.aux != nullptr && blk == 0 && tid < NEWTON_SYNC_DOUBLES) op.aux[tid] = 0.0;   // arm k_newton's arrival counter
+        if (op.aux != nullptr && blk == 0) for (int i = tid; i < NEWTON_SYNC_DOUBLES; i += 256) op.aux[i] = 0.0;   // arm k_newton's arrival counter
         if (DBUF) __syncthreads();           // next fragments landed (vmcnt(0) + barrier), stores done
     }
 }
@@ -489,6 +489,7 @@ __global__ __launch_bounds__(256, 3) void k_newton(const ModelDev *__restrict__ 
     __shared__ double exl[NCAT * NS][2];          // (exp(lambda_i r_k t), lambda_i r_k)
     __shared__ double red[3][4];
     __shared__ double bc[4];
+    __shared__ double gp[3][NEWTON_MAX_SPLIT];
     const NewtonReq r = reqs[blockIdx.y];
     const int tid = threadIdx.x, mpad = r.mpad, wg = blockIdx.x;
     const size_t M = (size_t)mpad;
@@ -562,9 +563,16 @@ __global__ __launch_bounds__(256, 3) void k_newton(const ModelDev *__restrict__ 
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > 20000000L) { bc[3] = 1.0; break; }      // bounded: never hang the GPU
                 }
-                double tot[3] = {0.0, 0.0, 0.0};
+            }
+            __syncthreads();
+            {   // every slice's partials, one lane per slice; summed by one thread in slice order (bit-reproducible)
                 const double *base = part + (nevals & 1) * NEWTON_MAX_SPLIT * 3;
-                for (int w = 0; w < S; ++w) { tot[0] += ld_agent(base + w * 3); tot[1] += ld_agent(base + w * 3 + 1); tot[2] += ld_agent(base + w * 3 + 2); }
+                if (tid < S) { gp[0][tid] = ld_agent(base + tid * 3); gp[1][tid] = ld_agent(base + tid * 3 + 1); gp[2][tid] = ld_agent(base + tid * 3 + 2); }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                double tot[3] = {0.0, 0.0, 0.0};
+                for (int w = 0; w < S; ++w) { tot[0] += gp[0][w]; tot[1] += gp[1][w]; tot[2] += gp[2][w]; }
                 bc[0] = tot[0]; bc[1] = tot[1]; bc[2] = tot[2];
             }
             __syncthreads();
@@ -667,7 +675,10 @@ void launch_newton(const ModelDev *model, const NewtonReq *reqs, int n, int max_
     if (n <= 0) return;
     int S = (max_mpad + 127) / 128;       // grid width; each request uses its own split (k_newton)
     S = S < 1 ? 1 : (S > NEWTON_MAX_SPLIT ? NEWTON_MAX_SPLIT : S);
-    const int chunk = 1024 / S;          // S * chunk workgroups of 256 threads are co-resident on 256 CUs
+    // Not every workgroup of the launch has to be resident at once: workgroups are dispatched in grid order (x
+    // fastest, round-robin over the XCDs), so the lowest unfinished request always has all of its <= 64 slices
+    // resident or next in line on every XCD and can finish; later requests spin (bounded) until their turn.
+    const int chunk = 32768;
     for (int off = 0; off < n; off += chunk) {
         const int m = (n - off < chunk) ? n - off : chunk;
         hipLaunchKernelGGL(k_newton, dim3(S, m), dim3(256), 0, s, model, reqs + off);

@@ -93,10 +93,10 @@ def constraints_from_tree(newick):
 class Context:
     """One engine context = one HIP device + stream (one per rank / per GPU)."""
 
-    def __init__(self, device=0, profile=False):
+    def __init__(self, device=0, profile=False, arena_bytes=0):
         self.L = _lib.load()
         self.ptr = C.c_void_p()
-        cfg = _lib.Config(device, int(profile), 0)
+        cfg = _lib.Config(device, int(profile), int(arena_bytes))
         rc = self.L.pml_create(C.byref(cfg), C.byref(self.ptr))
         if rc:
             raise PmlError(rc, self.L.pml_last_error(None).decode())
