@@ -35,6 +35,7 @@ int Ctx::init(int dev, bool prof) {
     device = dev; profile = prof;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
     return 0;
 }
 void Ctx::destroy() {
@@ -47,7 +48,8 @@ void Ctx::destroy() {
     if (arena_cache) hipFree(arena_cache);
     arena_cache = nullptr; arena_cache_bytes = 0;
     if (stream) hipStreamDestroy(stream);
-    stream = nullptr;
+    if (stream2) hipStreamDestroy(stream2);
+    stream = stream2 = nullptr;
 }
 int Ctx::ensure_model(int pm) {
     Ctx *ctx = this;
@@ -75,12 +77,12 @@ void Ctx::tic(int kind, double bytes) {
     stats[kind].launches++; stats[kind].bytes += bytes;
     if (!profile) return;
     Ev ev{kind, get_event(), get_event()};
-    hipEventRecord(ev.a, stream);
+    hipEventRecord(ev.a, tic_stream ? tic_stream : stream);
     pending.push_back(ev);
 }
 void Ctx::toc() {
     if (!profile) return;
-    hipEventRecord(pending.back().b, stream);
+    hipEventRecord(pending.back().b, tic_stream ? tic_stream : stream);
 }
 void Ctx::resolve_events() {
     for (auto &e : pending) {
@@ -204,7 +206,10 @@ void Batch::destroy() {
     if (d_stage) hipFree(d_stage);
     if (d_frags) hipFree(d_frags);
     if (d_nsync) hipFree(d_nsync);
-    d_nsync = nullptr;
+    if (ev_stagger) { hipEventDestroy(ev_stagger); ev_stagger = nullptr; }
+    if (d_nsync2) hipFree(d_nsync2);
+    if (d_frags2) hipFree(d_frags2);
+    d_nsync = d_nsync2 = nullptr; d_frags2 = nullptr; nsync_cap = nsync_cap2 = 0; frag_cap2 = 0;
     if (plan.h) hipHostFree(plan.h);
     if (plan.d) hipFree(plan.d);
     plan = Plan();
@@ -319,6 +324,7 @@ int Batch::create_replicates(Ctx *c, const GeneStore &store, const std::vector<s
 
 int Batch::chain_sync() {
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream2));
     HIPCHK(hipGetLastError());
     ctx->resolve_events();
     chain_off = 0;
@@ -358,13 +364,15 @@ int Batch::ensure_stage(size_t bytes) {
     return 0;
 }
 int Batch::ensure_frags(size_t sets) {
-    if (sets <= frag_cap) return 0;
+    double *&fr = lane ? d_frags2 : d_frags; size_t &fc = lane ? frag_cap2 : frag_cap;
+    if (sets <= fc) return 0;
     if (chain) { if (int rc = chain_sync()) return rc; }
     const size_t cap = std::max(sets * 5 / 4, (size_t)256);
-    if (d_frags) hipFree(d_frags);
-    d_frags = nullptr; frag_cap = 0; plan.valid = false;      // cached descriptors point into d_frags
-    HIPCHK(hipMalloc((void **)&d_frags, cap * FRAG_STRIDE * sizeof(double)));
-    frag_cap = cap;
+    if (fr) hipFree(fr);
+    fr = nullptr; fc = 0;
+    if (!lane) plan.valid = false;      // cached descriptors point into d_frags
+    HIPCHK(hipMalloc((void **)&fr, cap * FRAG_STRIDE * sizeof(double)));
+    fc = cap;
     return 0;
 }
 
@@ -489,14 +497,18 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     const size_t nreq_max = 10 * nops + 9 * ntail;         // <= 5 requests per side (pitchfork: 3 tables + 2 fragment sets)
     bool any_pitch = false;
     if (int rc = ensure_frags(std::max(nreq_max, (size_t)1))) return rc;
-    if (nnewton > nsync_cap) {
+    double *&nsync_buf = lane ? d_nsync2 : d_nsync; size_t &nsync_c = lane ? nsync_cap2 : nsync_cap;
+    if (nnewton > nsync_c) {
         if (chain) { if (int rc = chain_sync()) return rc; }
-        if (d_nsync) hipFree(d_nsync);
-        d_nsync = nullptr; nsync_cap = 0;
+        if (nsync_buf) hipFree(nsync_buf);
+        nsync_buf = nullptr; nsync_c = 0;
         const size_t cap = std::max(nnewton * 2, (size_t)256);
-        HIPCHK(hipMalloc((void **)&d_nsync, cap * NEWTON_SYNC_DOUBLES * sizeof(double)));
-        nsync_cap = cap;
+        HIPCHK(hipMalloc((void **)&nsync_buf, cap * NEWTON_SYNC_DOUBLES * sizeof(double)));
+        nsync_c = cap;
     }
+    const hipStream_t st = lane ? ctx->stream2 : ctx->stream;
+    double *const frags_buf = lane ? d_frags2 : d_frags;
+    ctx->tic_stream = st;
     const size_t ngenes = genes.size();
     const size_t o_req = 0;
     const size_t o_ops = align_up(o_req + nreq_max * sizeof(PmatReq), 256);
@@ -526,7 +538,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         r.t = t; std::memcpy(r.rates, genes[g].rates, sizeof r.rates); r.kind = kind; r.pad = 0;
         r.tp = (chain && v >= 0 && genes[g].len_pending[(size_t)v * 3 + q]) ? genes[g].d_len + (size_t)v * 3 + q : nullptr;
         last_src.push_back({(int)g, v, q, kind});
-        return d_frags + (ireq++) * FRAG_STRIDE;
+        return frags_buf + (ireq++) * FRAG_STRIDE;
     };
     // resolves one side of an op: pointers, kind, scaling counts; `want_table`: newview tip sides look
     // their contraction up in a tip table; `t_branch`/(bv,bq): the branch between this side and the op
@@ -604,13 +616,13 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             } else {
                 d.pl = eig; d.pr = eig + PFRAG;
                 d.out = G.d_sumtab[t.slot]; d.out_scl = G.d_sumscl[t.slot];
-                d.aux = d_nsync + (size_t)in * NEWTON_SYNC_DOUBLES;
+                d.aux = nsync_buf + (size_t)in * NEWTON_SYNC_DOUBLES;
                 NewtonReq &nr = hnewt[in];
                 nr.sumtab = G.d_sumtab[t.slot]; nr.weight = G.d_weight; nr.scl = G.d_sumscl[t.slot];
                 std::memcpy(nr.rates, G.rates, sizeof nr.rates);
                 nr.t0 = t.t0; nr.tol = newton_tol; nr.out = result; nr.mpad = mp; nr.max_iter = t.max_iter;
                 nr.t_dev0 = t.t_dev0; nr.t_dev1 = t.t_dev1;
-                nr.sync = d_nsync + (size_t)in * NEWTON_SYNC_DOUBLES; newton_maxm = std::max(newton_maxm, mp);
+                nr.sync = nsync_buf + (size_t)in * NEWTON_SYNC_DOUBLES; newton_maxm = std::max(newton_maxm, mp);
                 algo_bytes += (double)G.aln.npat * (L.bytes + R.bytes + 640);
                 in++;
             }
@@ -660,30 +672,32 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         run.op_end = (int)nout;
     }
 
-    HIPCHK(hipMemcpyAsync(ds, hs, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ds, hs, bytes, hipMemcpyHostToDevice, st));
     const ModelDev *md = ctx->d_model[pi_mode];
     if (ireq) {
         ctx->tic(K_PMAT, (double)ireq * PFRAG * 8);
-        launch_pmat(md, (const PmatReq *)(ds + o_req), d_frags, (int)ireq, ctx->stream);
+        launch_pmat(md, (const PmatReq *)(ds + o_req), frags_buf, (int)ireq, st);
         ctx->toc();
     }
     if (nruns) {
         ctx->tic(K_NEWVIEW, algo_bytes);
-        launch_oplist((const NvOp *)(ds + o_ops), (const GeneRun *)(ds + o_runs), (int)nruns, max_mpad, any_pitch, ctx->stream);
+        launch_oplist((const NvOp *)(ds + o_ops), (const GeneRun *)(ds + o_runs), (int)nruns, max_mpad, any_pitch, st);
         ctx->toc();
     }
+    if (record_stagger) { record_stagger = false; hipEventRecord(ev_stagger, st); }
     if (neval) {
         ctx->tic(K_REDUCE, 0);
-        launch_reduce((const ReduceReq *)(ds + o_red), (int)neval, ctx->stream);
+        launch_reduce((const ReduceReq *)(ds + o_red), (int)neval, st);
         ctx->toc();
     }
     if (nnewton) {
         double nb = 0;
         for (auto &t : tails) if (t.mode != MODE_EVALUATE) nb += (double)genes[t.gene].aln.npat * 640;
         ctx->tic(K_NEWTON, nb);
-        launch_newton(md, (const NewtonReq *)(ds + o_newt), (int)nnewton, newton_maxm, ctx->stream);
+        launch_newton(md, (const NewtonReq *)(ds + o_newt), (int)nnewton, newton_maxm, st);
         ctx->toc();
     }
+    ctx->tic_stream = nullptr;
     const double t_launched = now_ms();
     ctx->stats[K_HOST_BUILD].launches++; ctx->stats[K_HOST_BUILD].ms += t_launched - t_begin;
     if (!chain) {
@@ -844,24 +858,45 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
     struct Done { int gene, v, w; double old; size_t idx; };
     std::vector<Done> done; done.reserve(nres);
     auto fail_out = [&](int rc) { if (chain) { chain_sync(); chain = false; } return rc; };
+    // two lanes: with enough genes the pass is issued as two independent halves (even / odd genes) on two streams.
+    // One half's latency-bound stretches (k_newton's cross-workgroup exchanges, k_pmat, kernel boundaries) then
+    // overlap the other half's HBM-bound CLV updates.  The gene -> lane map is fixed for the whole pass, so a
+    // gene's steps stay ordered on one stream.
+    static const bool no_lanes = std::getenv("PML_NO_LANES") != nullptr;
+    int nact = 0; for (int g = 0; g < n; ++g) nact += active[g] && !order[g].empty();
+    const bool two_lanes = chain && !no_lanes && nact >= 16;
     for (size_t step = 0; step < maxlen; ++step) {
         ++cnt_smooth;
-        std::vector<PendingOp> ops; std::vector<Tail> tails;
         const size_t first = done.size();
-        for (int g = 0; g < n; ++g) {
-            if (!active[g] || step >= order[g].size()) continue;
-            auto [v, w] = order[g][step];
-            Gene &G = genes[g];
-            need(g, v, w, ops); need(g, w, v, ops);
-            Tail t{g, msg(g, v, w), msg(g, w, v), MODE_SUMTABLE, G.tree.len[v][G.tree.slot(v, w)], 32};
-            if (chain) {
-                t.result_dev = d_chain + 4 * done.size();
-                t.t_dev0 = G.d_len + (size_t)v * 3 + G.tree.slot(v, w); t.t_dev1 = G.d_len + (size_t)w * 3 + G.tree.slot(w, v);
+        for (int ln = 0; ln < (two_lanes ? 2 : 1); ++ln) {
+            std::vector<PendingOp> ops; std::vector<Tail> tails;
+            for (int g = 0; g < n; ++g) {
+                if (!active[g] || step >= order[g].size()) continue;
+                if (two_lanes && (g & 1) != ln) continue;
+                auto [v, w] = order[g][step];
+                Gene &G = genes[g];
+                need(g, v, w, ops); need(g, w, v, ops);
+                Tail t{g, msg(g, v, w), msg(g, w, v), MODE_SUMTABLE, G.tree.len[v][G.tree.slot(v, w)], 32};
+                if (chain) {
+                    t.result_dev = d_chain + 4 * done.size();
+                    t.t_dev0 = G.d_len + (size_t)v * 3 + G.tree.slot(v, w); t.t_dev1 = G.d_len + (size_t)w * 3 + G.tree.slot(w, v);
+                }
+                done.push_back({g, v, w, t.t0, done.size()});
+                tails.push_back(t);
             }
-            done.push_back({g, v, w, t.t0, done.size()});
-            tails.push_back(t);
+            if (tails.empty()) continue;
+            lane = ln;
+            if (two_lanes && step == 0) {
+                // stagger the lanes by one CLV-update kernel so that one lane's k_newton (latency-bound) runs
+                // against the other's k_oplist (HBM-bound) instead of both doing the same thing at once
+                if (!ev_stagger) hipEventCreateWithFlags(&ev_stagger, hipEventDisableTiming);
+                if (ln == 0) record_stagger = true;
+                else hipStreamWaitEvent(ctx->stream2, ev_stagger, 0);
+            }
+            const int rc = run(ops, tails);
+            lane = 0;
+            if (rc) return fail_out(rc);
         }
-        if (int rc = run(ops, tails)) return fail_out(rc);
         if (chain) {                 // the new length is on the device only: later requests across (v,w) take it from d_len
             for (size_t i = first; i < done.size(); ++i) {
                 Gene &G = genes[done[i].gene]; const int v = done[i].v, w = done[i].w;

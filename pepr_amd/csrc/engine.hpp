@@ -19,6 +19,7 @@ struct Ctx {
     int device = 0;
     bool profile = false;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;      // second lane of a chained smoothing pass (half the genes each, overlapped)
     std::mutex mu;
     std::string last_error;
     Model model[2];
@@ -38,6 +39,7 @@ struct Ctx {
     void destroy();
     int ensure_model(int pi_mode);
     hipEvent_t get_event();
+    hipStream_t tic_stream = nullptr;    // stream the next tic/toc pair is recorded on (null = stream)
     void tic(int kind, double bytes);   // record start (profile mode)
     void toc();                          // record stop
     void resolve_events();               // after a stream sync
@@ -97,6 +99,10 @@ struct Batch {
     void *h_stage = nullptr; size_t h_cap = 0;
     void *d_stage = nullptr; size_t d_cap = 0;
     double *d_frags = nullptr; size_t frag_cap = 0;      // in fragment sets
+    double *d_frags2 = nullptr; size_t frag_cap2 = 0;    // lane 1
+    double *d_nsync2 = nullptr; size_t nsync_cap2 = 0;
+    int lane = 0;                                        // which stream / buffers the next run() uses (chained passes)
+    hipEvent_t ev_stagger = nullptr; bool record_stagger = false;   // lane 1 starts one k_oplist behind lane 0
     double *d_scalars = nullptr; double *h_scalars = nullptr;   // 8 doubles per gene
     double *d_nsync = nullptr; size_t nsync_cap = 0;             // Newton inter-workgroup sync blocks
     // cached descriptors of the full-traversal score of ALL genes (topology unchanged): replays skip

@@ -84,20 +84,27 @@ __global__ __launch_bounds__(256) void k_pmat(const ModelDev *__restrict__ md,
             for (int k = 0; k < NS; ++k) v += W[k] * sUi[k * NS + j];
             if (v < 0.0) v = 0.0;
             if (req.kind == PM_TIPTABLE) sP[row * NS + j] = v;
-            // fragment element (c, st = s/4, kk = j/4)[4*(j%4) + s%4]
-            else out[((c * 25 + (s2 >> 2) * 5 + (j >> 2)) << 4) + ((j & 3) << 2) + (s2 & 3)] = v * scale;
+            // fragment element (c, st = s/4, kk = j/4)[4*(j%4) + s%4]: staged in LDS, written out coalesced below
+            else sP[((c * 25 + (s2 >> 2) * 5 + (j >> 2)) << 4) + ((j & 3) << 2) + (s2 & 3)] = v * scale;
         }
     }
-    if (req.kind != PM_TIPTABLE) return;
     __syncthreads();
+    if (req.kind != PM_TIPTABLE) {
+        for (int idx = tid; idx < PFRAG; idx += 256) out[idx] = sP[idx];
+        return;
+    }
     for (int idx = tid; idx < TIPTAB_DOUBLES; idx += 256) {
         const int kk = idx & 7, q = (idx >> 3) & 3, code = (idx >> 5) % NCODES, c = (idx >> 5) / NCODES;
         double v = 0.0;
         if (kk < 5) {
-            const unsigned mask = code_mask((unsigned)code);
             const double *prow = sP + (c * NS + 4 * kk + q) * NS;
+            if (code < NS) v = prow[code];                          // a plain state: one column
+            else if (code == 20) v = prow[2] + prow[3];             // B = N | D  (same order as code_mask's bit walk)
+            else if (code == 21) v = prow[5] + prow[6];             // Z = Q | E
+            else {
 #pragma unroll
-            for (int j = 0; j < NS; ++j) if ((mask >> j) & 1u) v += prow[j];
+                for (int j = 0; j < NS; ++j) v += prow[j];          // gap / unknown: every state
+            }
         }
         out[idx] = v;
     }
