@@ -35,7 +35,12 @@ int Ctx::init(int dev, bool prof) {
     device = dev; profile = prof;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    {   // lane 1 gets a different priority class: HIP multiplexes same-priority streams onto a few hardware queues
+        // (4 by default), and two lanes that land on ONE queue run slower than a single lane
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+        HIPCHK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, hi));
+    }
     return 0;
 }
 void Ctx::destroy() {

@@ -2,6 +2,8 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+if os.environ.get('IMPORT_TORCH'):
+    import torch; torch.cuda.init(); torch.cuda.synchronize(); print('torch initialised')
 from pepr_amd import synth, engine
 ng = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 nt = int(sys.argv[2]) if len(sys.argv) > 2 else 50
