@@ -398,15 +398,31 @@ int pml_parsimony_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const pm
     for (int i = 0; i < n; ++i) std::memset(&out[i], 0, sizeof(pml_result));
     try {
         if (hipSetDevice(ctx->c.device) != hipSuccess) return ctx->c.fail(PML_EDEVICE, "hipSetDevice failed");
-        std::vector<Tree> trees; std::vector<EncodedAlignment> enc; std::vector<long long> len; std::vector<int> moves;
-        const int rc = parsimony_batch(&ctx->c, n, reinterpret_cast<const pml_alignment_view *>(alns), opts ? opts->seed : 0u,
-                                       opts ? opts->spr_radius : 20, trees, enc, len, moves);
-        if (rc) { for (int i = 0; i < n; ++i) out[i].status = rc; return rc; }
-        for (int i = 0; i < n; ++i) {
-            out[i].npatterns = enc[i].npat; out[i].nsites = enc[i].nsites;
-            out[i].newick = dup_string(trees[i].newick(enc[i].names, -1));
-            if (!out[i].newick) return ctx->c.fail(PML_ENOMEM, "host allocation failed");
-            if (mp_length) mp_length[i] = len[i];
+        // gene lists whose Fitch vectors do not fit in free HBM at once go through in consecutive sub-batches
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)1 << 40;
+        size_t budget = (size_t)(0.5 * (double)(free_b + ctx->c.arena_cache_bytes));
+        if (const char *e = std::getenv("PML_HBM_BUDGET_MB")) budget = (size_t)std::atoll(e) << 20;   // test hook
+        const int radius = opts ? opts->spr_radius : 20;
+        for (int begin = 0; begin < n;) {
+            size_t used = 0; int end = begin;
+            while (end < n) {
+                const size_t mp = ((size_t)std::max(alns[end].nsites, 1) + 31) / 32 * 32, nt = (size_t)std::max(alns[end].ntax, 3);
+                const size_t need = (4 * nt + 64 * (size_t)(radius + 2) + 8) * mp * 4;       // tips + 3 messages/node + path vectors of <= 64 groups
+                if (end > begin && used + need > budget) break;
+                used += need; ++end;
+            }
+            std::vector<Tree> trees; std::vector<EncodedAlignment> enc; std::vector<long long> len; std::vector<int> moves;
+            const int rc = parsimony_batch(&ctx->c, end - begin, reinterpret_cast<const pml_alignment_view *>(alns) + begin, opts ? opts->seed : 0u,
+                                           radius, trees, enc, len, moves);
+            if (rc) { for (int i = 0; i < n; ++i) out[i].status = rc; return rc; }
+            for (int i = begin; i < end; ++i) {
+                out[i].npatterns = enc[i - begin].npat; out[i].nsites = enc[i - begin].nsites;
+                out[i].newick = dup_string(trees[i - begin].newick(enc[i - begin].names, -1));
+                if (!out[i].newick) return ctx->c.fail(PML_ENOMEM, "host allocation failed");
+                if (mp_length) mp_length[i] = len[i - begin];
+            }
+            begin = end;
         }
     } catch (const std::bad_alloc &) { return ctx->c.fail(PML_ENOMEM, "host allocation failed"); }
     catch (const std::exception &e) { return ctx->c.fail(PML_EINVAL, e.what()); }

@@ -45,6 +45,15 @@ def test_parsimony_batch_ragged_and_ambiguity(gpu_ctx):
         assert engine.rf_distance(g["newick"], onw) == 0
 
 
+def test_parsimony_sub_batching(gpu_ctx, monkeypatch):
+    """gene lists larger than the HBM budget run as consecutive sub-batches with identical results"""
+    genes = [(lambda t: (t[0], t[1]))(synth.simulate_alignment(10 + i, 150 + 20 * i, 3000 + i)) for i in range(6)]
+    whole = gpu_ctx.parsimony(genes, seed=2, spr_radius=20)
+    monkeypatch.setenv("PML_HBM_BUDGET_MB", "1")
+    parts = gpu_ctx.parsimony(genes, seed=2, spr_radius=20)
+    assert [(p["newick"], p["length"]) for p in parts] == [(w["newick"], w["length"]) for w in whole]
+
+
 def test_parsimony_large_patterns_single_gene(gpu_ctx):
     """one long concatenation (many pattern blocks, prune groups spread over workgroups)"""
     names, rows, nw = synth.simulate_alignment(20, 6000, 77)
