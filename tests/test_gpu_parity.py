@@ -35,7 +35,9 @@ def test_golden_fixtures(gpu_ctx):
 
 @pytest.mark.parametrize("ntax,nsites,seed,alpha,miss", [
     (3, 17, 1, 1.0, 0.0), (4, 60, 3, 0.7, 0.0), (8, 300, 5, 2.5, 0.0), (12, 2000, 7, 0.8, 0.3),
-    (50, 1000, 1, 0.8, 0.0), (33, 31, 2, 0.05, 0.5), (6, 1, 9, 1.0, 0.0), (64, 129, 4, 50.0, 0.1)])
+    (50, 1000, 1, 0.8, 0.0), (33, 31, 2, 0.05, 0.5), (6, 1, 9, 1.0, 0.0), (64, 129, 4, 50.0, 0.1),
+    (200, 5000, 11, 0.8, 0.0),        # one gene of BASELINE config C4 at full size
+    (500, 2000, 12, 0.8, 0.2)])       # one gene of config C5 at full size, 20 % of the taxa absent (all '?')
 def test_score_vs_oracle(gpu_ctx, oracle_lib, ntax, nsites, seed, alpha, miss):
     names, rows, nw = synth.simulate_alignment(ntax, nsites, seed, missing_frac=miss)
     a, t, e = _oracle(oracle_lib, names, rows, nw, alpha)
@@ -190,6 +192,28 @@ def test_full_size_properties_c3(gpu_ctx):
         assert abs(out[g]["lnl"] - l1[g]) < 1e-8 * abs(l1[g])
     dup = [(G[0][0], [r + r for r in G[0][1]])]
     assert abs(gpu_ctx.score(dup, NW[:1], alpha=0.8)[0]["lnl"] - 2 * l1[0]) < 1e-8 * abs(l1[0])
+
+
+def test_full_size_search_properties_c3(gpu_ctx):
+    """Config C3 at full size through the search (NJ + optimisation + NNI), oracle-free properties: determinism,
+    the returned Newick + alpha re-score to the returned lnL, the result is at least as likely as the optimised
+    generating tree for nearly every gene, and RF to the generating tree is small."""
+    genes = synth.simulate_genes(128, 50, 1000)
+    G = [(g[0], g[1]) for g in genes]
+    a = gpu_ctx.search(G, None, nni=True, spr_radius=0, epsilon=1e-3)
+    b = gpu_ctx.search(G, None, nni=True, spr_radius=0, epsilon=1e-3)
+    assert [x["newick"] for x in a] == [x["newick"] for x in b] and [x["lnl"] for x in a] == [x["lnl"] for x in b]
+    from pepr_amd import engine
+    bat = engine.Batch(gpu_ctx, G, [x["newick"] for x in a], alpha=1.0)
+    for g in range(128):
+        bat.set_alpha(a[g]["alpha"], g)
+    re = bat.score(); bat.close()
+    assert np.max(np.abs(re - np.array([x["lnl"] for x in a])) / np.abs(re)) < 1e-9
+    true_opt = gpu_ctx.optimize(G, [g[2] for g in genes], epsilon=1e-3)
+    worse = sum(x["lnl"] < t["lnl"] - 0.5 for x, t in zip(a, true_opt))
+    assert worse <= 6, worse
+    rf = [engine.rf_distance(genes[i][2], a[i]["newick"]) for i in range(128)]
+    assert np.mean(rf) < 0.5 and max(rf) <= 4
 
 
 def test_nj_start_tree_matches_oracle(gpu_ctx, oracle_lib):
