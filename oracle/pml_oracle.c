@@ -745,28 +745,38 @@ static double eng_smooth(po_engine *e, po_tree *t, double thr) {
 
 /* Brent maximisation of lnL over alpha on log scale */
 static double eng_alpha_obj(po_engine *e, po_tree *t, double la) { po_engine_set_alpha(e, exp(la)); return -po_engine_lnl(e, t, NULL); }
-static double eng_opt_alpha(po_engine *e, po_tree *t) {
-    const double gold = 0.3819660112501051, tol = 1e-4;
-    double a = log(PO_ALPHA_MIN), b = log(PO_ALPHA_MAX);
-    double x = log(e->alpha), w = x, v = x, fx = eng_alpha_obj(e, t, x), fw = fx, fv = fx, d = 0, ee = 0;
-    /* shrink bracket around current alpha to speed up: +-ln(4) window, widened if at edge */
-    for (int it = 0; it < 60; it++) {
-        double xm = 0.5 * (a + b), tol1 = tol * fabs(x) + 1e-6, tol2 = 2 * tol1;
-        if (fabs(x - xm) <= tol2 - 0.5 * (b - a)) break;
-        int golden = 1; double u;
-        if (fabs(ee) > tol1) {
-            double r = (x - w) * (fx - fv), q = (x - v) * (fx - fw), p = (x - v) * q - (x - w) * r;
-            q = 2 * (q - r); if (q > 0) p = -p; q = fabs(q);
-            double etemp = ee; ee = d;
-            if (!(fabs(p) >= fabs(0.5 * q * etemp) || p <= q * (a - x) || p >= q * (b - x))) {
-                d = p / q; u = x + d; if (u - a < tol2 || b - u < tol2) d = (xm - x >= 0) ? tol1 : -tol1; golden = 0;
+/* Brent on log(alpha) with tolerance tol, bracketed like RAxML brackets its model parameters: a window of
+ * +-ln 4 around the current value (clipped to [ALPHA_MIN, ALPHA_MAX]); if the minimum ends at an edge of the
+ * window that is not a global limit, the search continues from there in a window twice as wide */
+static double eng_opt_alpha(po_engine *e, po_tree *t, double tol) {
+    const double gold = 0.3819660112501051;
+    const double LMIN = log(PO_ALPHA_MIN), LMAX = log(PO_ALPHA_MAX);
+    double x = log(e->alpha), fx = eng_alpha_obj(e, t, x), W = log(4.0);
+    for (int win = 0; win < 8; win++) {
+        double a = x - W > LMIN ? x - W : LMIN, b = x + W < LMAX ? x + W : LMAX;
+        const double lo = a, hi = b;
+        double w = x, v = x, fw = fx, fv = fx, d = 0, ee = 0;
+        for (int it = 0; it < 60; it++) {
+            double xm = 0.5 * (a + b), tol1 = tol * fabs(x) + 1e-6, tol2 = 2 * tol1;
+            if (fabs(x - xm) <= tol2 - 0.5 * (b - a)) break;
+            int golden = 1; double u;
+            if (fabs(ee) > tol1) {
+                double r = (x - w) * (fx - fv), q = (x - v) * (fx - fw), p = (x - v) * q - (x - w) * r;
+                q = 2 * (q - r); if (q > 0) p = -p; q = fabs(q);
+                double etemp = ee; ee = d;
+                if (!(fabs(p) >= fabs(0.5 * q * etemp) || p <= q * (a - x) || p >= q * (b - x))) {
+                    d = p / q; u = x + d; if (u - a < tol2 || b - u < tol2) d = (xm - x >= 0) ? tol1 : -tol1; golden = 0;
+                }
             }
+            if (golden) { ee = (x >= xm) ? a - x : b - x; d = gold * ee; }
+            u = (fabs(d) >= tol1) ? x + d : x + (d >= 0 ? tol1 : -tol1);
+            double fu = eng_alpha_obj(e, t, u);
+            if (fu <= fx) { if (u >= x) a = x; else b = x; v = w; fv = fw; w = x; fw = fx; x = u; fx = fu; }
+            else { if (u < x) a = u; else b = u; if (fu <= fw || w == x) { v = w; fv = fw; w = u; fw = fu; } else if (fu <= fv || v == x || v == w) { v = u; fv = fu; } }
         }
-        if (golden) { ee = (x >= xm) ? a - x : b - x; d = gold * ee; }
-        u = (fabs(d) >= tol1) ? x + d : x + (d >= 0 ? tol1 : -tol1);
-        double fu = eng_alpha_obj(e, t, u);
-        if (fu <= fx) { if (u >= x) a = x; else b = x; v = w; fv = fw; w = x; fw = fx; x = u; fx = fu; }
-        else { if (u < x) a = u; else b = u; if (fu <= fw || w == x) { v = w; fv = fw; w = u; fw = fu; } else if (fu <= fv || v == x || v == w) { v = u; fv = fu; } }
+        const double edge = 4 * (tol * fabs(x) + 1e-6);
+        if ((x - lo < edge && lo > LMIN) || (hi - x < edge && hi < LMAX)) { W *= 2; continue; }
+        break;
     }
     po_engine_set_alpha(e, exp(x));
     return -fx;
@@ -790,7 +800,7 @@ double po_engine_optimize(po_engine *e, po_tree *t, int opt_alpha, double eps) {
          * lengths are not polished to thr (they shift again with the next alpha) */
         int budget = opt_alpha ? (1 << (round < 5 ? round : 5)) : maxpass; if (budget > maxpass) budget = maxpass;
         for (int pass = 0; pass < budget; pass++) { if (eng_smooth(e, t, thr) < thr) break; }
-        double nl = opt_alpha ? eng_opt_alpha(e, t) : po_engine_lnl(e, t, NULL);
+        double nl = opt_alpha ? eng_opt_alpha(e, t, eps >= 0.05 ? 1e-2 : 1e-4) : po_engine_lnl(e, t, NULL);
         double gain = nl - lnl; lnl = nl;
         if (gain < eps) break;
     }

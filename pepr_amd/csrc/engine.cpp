@@ -35,12 +35,7 @@ int Ctx::init(int dev, bool prof) {
     device = dev; profile = prof;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    {   // lane 1 gets a different priority class: HIP multiplexes same-priority streams onto a few hardware queues
-        // (4 by default), and two lanes that land on ONE queue run slower than a single lane
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
-        HIPCHK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, hi));
-    }
+    HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
     return 0;
 }
 void Ctx::destroy() {
@@ -867,9 +862,14 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
     // One half's latency-bound stretches (k_newton's cross-workgroup exchanges, k_pmat, kernel boundaries) then
     // overlap the other half's HBM-bound CLV updates.  The gene -> lane map is fixed for the whole pass, so a
     // gene's steps stay ordered on one stream.
-    static const bool no_lanes = std::getenv("PML_NO_LANES") != nullptr;
+    // OFF by default (PML_LANES=1 turns it on): the gain is 3-5 % at best and depends on the two streams landing on
+    // different hardware queues -- HIP multiplexes same-priority streams onto 4 queues, and in a process with more
+    // streams (torch, a second context) both lanes shared one queue and ran 25 % slower than a single lane; putting
+    // lane 1 in another priority class fixed C3 but doubled the C4-shard search time (the high-priority lane starves
+    // the other lane's spinning k_newton workgroups).
+    static const bool lanes_on = std::getenv("PML_LANES") != nullptr;
     int nact = 0; for (int g = 0; g < n; ++g) nact += active[g] && !order[g].empty();
-    const bool two_lanes = chain && !no_lanes && nact >= 16;
+    const bool two_lanes = chain && lanes_on && nact >= 16;
     for (size_t step = 0; step < maxlen; ++step) {
         ++cnt_smooth;
         const size_t first = done.size();
@@ -936,19 +936,32 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
     return 0;
 }
 
-int Batch::opt_alpha(const std::vector<char> &active, double *lnl) {
+// Brent on log(alpha) per gene, all genes in lock step (one full-traversal evaluation of every active gene per
+// iteration).  Control flow = the oracle's eng_opt_alpha: +-ln 4 window around the current value, doubled and
+// continued when the minimum ends at a window edge that is not a global limit.
+int Batch::opt_alpha(const std::vector<char> &active, double *lnl, double tol) {
     const int n = (int)genes.size();
+    const double LMIN = std::log(ALPHA_MIN), LMAX = std::log(ALPHA_MAX);
     std::vector<Brent> br(n);
     std::vector<char> act(active);
-    std::vector<double> f(n);
+    std::vector<double> f(n), W(n, std::log(4.0)), lo(n), hi(n);
+    std::vector<int> win(n, 0);
     if (int rc = score(act, f.data())) return rc;
-    for (int g = 0; g < n; ++g) if (act[g]) br[g].start(std::log(ALPHA_MIN), std::log(ALPHA_MAX), std::log(genes[g].alpha), -f[g]);
+    auto open_window = [&](int g, double x, double fx) {
+        lo[g] = std::max(LMIN, x - W[g]); hi[g] = std::min(LMAX, x + W[g]);
+        br[g].start(lo[g], hi[g], x, fx, tol);
+    };
+    for (int g = 0; g < n; ++g) if (act[g]) open_window(g, std::log(genes[g].alpha), -f[g]);
     for (;;) {
         bool any = false;
         for (int g = 0; g < n; ++g) {
             if (!act[g]) continue;
-            if (br[g].propose()) { set_alpha(g, std::exp(br[g].u)); any = true; }
-            else act[g] = 0;
+            for (;;) {
+                if (br[g].propose()) { set_alpha(g, std::exp(br[g].u)); any = true; break; }
+                const double x = br[g].x, edge = 4 * (tol * std::fabs(x) + 1e-6);
+                if (++win[g] < 8 && ((x - lo[g] < edge && lo[g] > LMIN) || (hi[g] - x < edge && hi[g] < LMAX))) { W[g] *= 2; open_window(g, x, br[g].fx); continue; }
+                act[g] = 0; break;
+            }
         }
         if (!any) break;
         if (int rc = score(act, f.data())) return rc;
@@ -992,7 +1005,7 @@ int Batch::optimize(bool opt_alpha_flag, double eps, double *lnl, const std::vec
             if (int rc = smooth_pass(sm, md, thr)) return rc;
             for (int g = 0; g < n; ++g) if (sm[g] && md[g] < thr) sm[g] = 0;
         }
-        if (opt_alpha_flag) { if (int rc = opt_alpha(active, nl.data())) return rc; }
+        if (opt_alpha_flag) { if (int rc = opt_alpha(active, nl.data(), eps >= 0.05 ? 1e-2 : 1e-4)) return rc; }
         else { if (int rc = evaluate(active, nl.data())) return rc; }
         for (int g = 0; g < n; ++g) {
             if (!active[g]) continue;

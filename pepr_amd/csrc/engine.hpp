@@ -149,7 +149,7 @@ struct Batch {
     // one pass over the DIRTY branches (DFS order); a branch that moves by more than thr flags itself and
     // its neighbours for the next pass
     int smooth_pass(const std::vector<char> &active, std::vector<double> &maxdelta, double thr);
-    int opt_alpha(const std::vector<char> &active, double *lnl);
+    int opt_alpha(const std::vector<char> &active, double *lnl, double tol = 1e-4);
     int optimize(bool opt_alpha_flag, double eps, double *lnl, const std::vector<char> *mask = nullptr);
     int light_smooth(const std::vector<char> &active, double *lnl);
     int nni_round(const std::vector<char> &active, std::vector<double> &lnl, std::vector<int> &applied);

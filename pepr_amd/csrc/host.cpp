@@ -601,11 +601,11 @@ Tree nj_from_counts(int n, const std::vector<int64_t> &cmpc, const std::vector<i
 // ------------------------------------------------------------------------------------------
 // Brent (state machine form)
 // ------------------------------------------------------------------------------------------
-void Brent::start(double lo, double hi, double x0, double fx0) {
-    a = lo; b = hi; x = w = v = x0; fx = fw = fv = fx0; d = e = 0; iter = 0; done = false; u = x0;
+void Brent::start(double lo, double hi, double x0, double fx0, double tol_) {
+    a = lo; b = hi; x = w = v = x0; fx = fw = fv = fx0; d = e = 0; iter = 0; done = false; u = x0; tol = tol_;
 }
 bool Brent::propose() {
-    const double gold = 0.3819660112501051, tol = 1e-4;
+    const double gold = 0.3819660112501051;
     if (done || iter >= 60) { done = true; return false; }
     const double xm = 0.5 * (a + b), tol1 = tol * std::fabs(x) + 1e-6, tol2 = 2 * tol1;
     if (std::fabs(x - xm) <= tol2 - 0.5 * (b - a)) { done = true; return false; }

@@ -82,9 +82,9 @@ Tree nj_from_counts(int n, const std::vector<int64_t> &cmp, const std::vector<in
 
 // resumable Brent minimiser on a fixed interval (same control flow as the oracle's eng_opt_alpha)
 struct Brent {
-    double a, b, x, w, v, fx, fw, fv, d, e, u;
+    double a, b, x, w, v, fx, fw, fv, d, e, u, tol = 1e-4;
     int iter; bool done;
-    void start(double lo, double hi, double x0, double fx0);
+    void start(double lo, double hi, double x0, double fx0, double tol_ = 1e-4);
     bool propose();            // sets u; returns false when converged
     void update(double fu);
 };
