@@ -21,6 +21,7 @@
  *                        `raxmlHPC -f d -y` -> RAxML_parsimonyTree.<run> (topology only); the caller then
  *                        runs pml_optimize on it, as the reference runs `-f e -t` (:253-272)
  *   pml_bootstrap  <- .../pepr/tree/RAxMLRunner.java:115-132,302-318 (`-f a -x -N`, bootstrapReps > 0)
+ *   pml_sh_support <- .../pepr/tree/FastTreeRunner.java:67-70 (`FastTree_WAG -gamma` without -nosupport)
  *   pml_concatenate<- .../pepr/alignment/MSAConcatenator.java:78-189 (sorted taxon union, '?' padding)
  *   pml_refine_next<- .../pepr/tree/PhylogeneticTreeRefiner.java:298-359 + AdvancedTree.java:1061-1098
  *   pml_support_tree<- .../pepr/tree/TreeSupportDecorator.java:86-163 addSupportValues(): integer
@@ -184,6 +185,16 @@ int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *genes, const pm
  * refinedSubsets).  mean_out (optional) = floor(mean descendant support) per node in order of appearance. */
 int pml_refine_next(const char *supported_newick, int cutoff, int ndone, const char *const *done,
                     char **ingroup_out, int *nnodes_out, int **mean_out /* pml_free */);
+/* SH-like local supports, FastTree's default output when -nosupport is absent (FastTreeRunner.java:67-70: PEPR drops
+ * -nosupport when bootstrapReps > 0; AdvancedTree.getBranchSupports :484-506 reads the 0-1 labels x100).  For every
+ * internal split of the given tree (lengths and model->alpha as given): the split's arrangement against its two NNI
+ * alternatives, `nboot` (FastTree: 1000) resamples of the alignment columns on the device, support = share of
+ * resamples that do not overturn the observed advantage (FastTree 2.1 SHSupport / Guindon et al. 2010).
+ * out[i].newick carries the supports as inner labels with 3 decimals; lnl = lnL of the tree. */
+int pml_sh_support(pml_ctx *ctx, const pml_alignment *aln, const char *newick, const pml_model *model,
+                   int nboot, unsigned long long seed, pml_result *out);
+int pml_sh_support_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks,
+                         const pml_model *model, int nboot, unsigned long long seed, pml_result *out);
 /* Maximum-parsimony trees (Fitch lengths on the device): randomised stepwise addition (seed 0 =
  * input order) then SPR hill climbing within spr_radius edges (0 = none; RAxML uses 20).  out[i].newick is
  * topology only; out[i].lnl / alpha / tree_length are 0; mp_length[i] (optional) = weighted Fitch length. */

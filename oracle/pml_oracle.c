@@ -987,6 +987,74 @@ static int nni_round(po_engine *e, po_tree *t, double *lnl) {
     return applied;
 }
 
+/* ---- SH-like local supports (FastTree 2.1 `SHSupport`, the default output of `FastTree_WAG -gamma` without
+ * -nosupport, reference call site FastTreeRunner.java:67-70; Guindon et al. 2010).  For every internal edge in
+ * nni_round's order: per-pattern lnL of the current arrangement and of its two NNI alternatives, each with its central
+ * branch Newton-optimised (tolerance 1e-8) and nothing else re-optimised; nboot resamples of the alignment columns
+ * drawn by the counter hash col(r, j) = mix64((seed+1)*0x9E3779B97F4A7C15 + r*nsites + j) % nsites; sums are centred
+ * on the original totals; a resample supports the split when (best - second best) < observed delta = L0 - max(L1, L2);
+ * delta <= 0 gives support 0.  PARITY UNPINNED vs the FastTree binary (its RNG stream cannot be reproduced). ---- */
+static unsigned long long mix64(unsigned long long z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+    return z;
+}
+static void sumtab_pat_lnl(po_engine *e, double tt, const int *scale, double *out) {
+    int K = e->K, np = e->npat;
+    double ex[PO_MAXCAT][PO_NS];
+    for (int c = 0; c < K; c++) for (int i = 0; i < 20; i++) ex[c][i] = exp(e->m->eval[i] * e->rates[c] * tt);
+    for (int p = 0; p < np; p++) {
+        const double *s = e->sumtab + (size_t)p * K * 20; double f = 0;
+        for (int c = 0; c < K; c++) for (int i = 0; i < 20; i++) f += s[c * 20 + i] * ex[c][i];
+        out[p] = log(f / K) - scale[p] * PO_LOG_2_256;
+    }
+}
+int po_engine_sh_support(po_engine *e, const po_tree *t, int nboot, unsigned long long seed, double *support) {
+    int n = e->ntax, np = e->npat, K = e->K, ns = e->a->nsites, nedge = 0;
+    const double save = e->ntol; e->ntol = 1e-8;
+    (void)po_engine_lnl(e, t, NULL);
+    double *X = (double *)malloc(sizeof(double) * (size_t)np * K * 20), *Y = (double *)malloc(sizeof(double) * (size_t)np * K * 20);
+    int *xs = (int *)malloc(sizeof(int) * np), *ys = (int *)malloc(sizeof(int) * np), *sc = (int *)malloc(sizeof(int) * np);
+    double *l[3]; for (int i = 0; i < 3; i++) l[i] = (double *)malloc(sizeof(double) * np);
+    for (int u = n; u < t->nnodes; u++) for (int k = 0; k < 3; k++) {
+        int v = t->nbr[u][k]; if (v < n || v < u) continue;
+        int a[2], c[2]; double la[2], lc[2];
+        others(t, u, v, a, la); others(t, v, u, c, lc);
+        double t0 = t->len[u][k], tt;
+        eng_sumtable(e, t, u, v, sc); tt = eng_newton_branch(e, t0, NULL); sumtab_pat_lnl(e, tt, sc, l[0]);
+        for (int alt = 1; alt <= 2; alt++) {
+            int y = (alt == 1) ? 0 : 1;
+            side sa = eng_side(e, t, a[0], u), sb = eng_side(e, t, a[1], u), sy = eng_side(e, t, c[y], v), sz = eng_side(e, t, c[1 - y], v);
+            nv_core(e, sa, sy, la[0], lc[y], X, xs);
+            nv_core(e, sb, sz, la[1], lc[1 - y], Y, ys);
+            side SX = {X, xs, 0}, SY = {Y, ys, 0};
+            sumtable_core(e, SX, SY, sc); tt = eng_newton_branch(e, t0, NULL); sumtab_pat_lnl(e, tt, sc, l[alt]);
+        }
+        double orig[3] = {0, 0, 0};
+        for (int j = 0; j < ns; j++) { int p = e->a->site2pat[j]; for (int i = 0; i < 3; i++) orig[i] += l[i][p]; }
+        double delta = orig[0] - (orig[1] > orig[2] ? orig[1] : orig[2]);
+        int cnt = 0;
+        if (delta > 0) {
+            unsigned long long base = (seed + 1ull) * 0x9E3779B97F4A7C15ull;
+            for (int b = 0; b < nboot; b++) {
+                double s[3] = {0, 0, 0};
+                unsigned long long k0 = base + (unsigned long long)b * (unsigned long long)ns;
+                for (int j = 0; j < ns; j++) { int p = e->a->site2pat[(int)(mix64(k0 + (unsigned long long)j) % (unsigned long long)ns)]; s[0] += l[0][p]; s[1] += l[1][p]; s[2] += l[2][p]; }
+                for (int i = 0; i < 3; i++) s[i] -= orig[i];
+                double best = s[0] > s[1] ? s[0] : s[1]; if (s[2] > best) best = s[2];
+                double second;
+                if (best == s[0]) second = s[1] > s[2] ? s[1] : s[2];
+                else if (best == s[1]) second = s[0] > s[2] ? s[0] : s[2];
+                else second = s[0] > s[1] ? s[0] : s[1];
+                if (best - second < delta) cnt++;
+            }
+        }
+        support[nedge++] = nboot > 0 ? (double)cnt / nboot : 0.0;
+    }
+    free(X); free(Y); free(xs); free(ys); free(sc); for (int i = 0; i < 3; i++) free(l[i]);
+    e->ntol = save;
+    return nedge;
+}
+
 /* ---- lazy SPR (spec mirrored by pepr_amd/csrc/search.cpp) ------------------------------------
  * For every inner node p and neighbour s (ascending): prune the subtree hanging off p through s
  * (p's other neighbours x,y get joined by one branch tx+ty) and try every edge within `radius`

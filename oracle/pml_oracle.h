@@ -101,6 +101,9 @@ void po_engine_branch_derivs(po_engine *e, const po_tree *t, int u, int v, doubl
 /* tree search: NJ start (or `start` if non-NULL), NNI (+SPR if spr_radius>0); returns lnL */
 double po_engine_search(po_engine *e, po_tree **t_inout, int spr_radius, double eps);
 po_tree *po_nj_tree(const po_aln *a);
+/* SH-like local supports (FastTree SHSupport): support[] in internal-edge order (u ascending, slot ascending, v > u inner);
+ * returns the number of edges written */
+int po_engine_sh_support(po_engine *e, const po_tree *t, int nboot, unsigned long long seed, double *support);
 
 /* ---- parsimony (`raxmlHPC -y` start tree; spec in pml_oracle.c) ---- */
 long long po_parsimony_length(const po_aln *a, const po_tree *t);     /* weighted Fitch length */

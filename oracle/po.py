@@ -63,6 +63,8 @@ def lib():
         L.po_engine_search.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_double]
         L.po_nj_tree.restype = vp
         L.po_nj_tree.argtypes = [vp]
+        L.po_engine_sh_support.restype = C.c_int
+        L.po_engine_sh_support.argtypes = [vp, vp, C.c_int, C.c_ulonglong, C.POINTER(C.c_double)]
         L.po_parsimony_length.restype = C.c_longlong
         L.po_parsimony_length.argtypes = [vp, vp]
         L.po_parsimony_tree.restype = vp
@@ -195,6 +197,12 @@ class Engine:
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         lib().po_engine_branch_derivs(self.ptr, tree.ptr, u, v, C.byref(a), C.byref(b), C.byref(c))
         return a.value, b.value, c.value
+
+    def sh_support(self, tree, nboot=1000, seed=314159):
+        """SH-like local supports in internal-edge order (numpy array)."""
+        out = np.zeros(max(self.aln.ntax - 3, 1))
+        k = lib().po_engine_sh_support(self.ptr, tree.ptr, nboot, seed, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out[:k]
 
     def search(self, start=None, spr_radius=0, eps=1e-3):
         """NJ start (or a copy of `start`), NNI hill climbing; returns (lnL, Tree)."""

@@ -374,6 +374,40 @@ int pml_support_tree(const char *main_newick, int ntrees, const char *const *sup
     return *out ? PML_OK : PML_ENOMEM;
 }
 
+int pml_sh_support_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks, const pml_model *model,
+                         int nboot, unsigned long long seed, pml_result *out) {
+    if (!ctx || !alns || !newicks || !out || n <= 0 || nboot <= 0) return PML_EINVAL;
+    for (int i = 0; i < n; ++i) { std::memset(&out[i], 0, sizeof(pml_result)); if (!newicks[i]) return ctx->c.fail(PML_EINVAL, "newick required"); }
+    std::lock_guard<std::mutex> lk(ctx->c.mu);
+    pml_batch *b = nullptr;
+    int rc = batch_create_impl(ctx, n, alns, newicks, model, false, &b);
+    if (rc) return rc;
+    try {
+        std::vector<std::vector<double>> sup; std::vector<std::vector<std::pair<int, int>>> edges;
+        rc = b->b.sh_support(nboot, seed, sup, edges);
+        std::vector<double> lnl(n);
+        if (!rc) rc = b->b.evaluate(std::vector<char>(n, 1), lnl.data());
+        for (int i = 0; i < n && !rc; ++i) {
+            const Gene &G = b->b.genes[i]; const Tree &T = G.tree;
+            std::vector<std::vector<double>> lab((size_t)T.nnodes(), std::vector<double>(3, -1.0));
+            for (size_t e = 0; e < edges[i].size(); ++e) {
+                const int u = edges[i][e].first, v = edges[i][e].second;
+                lab[u][T.slot(u, v)] = sup[i][e]; lab[v][T.slot(v, u)] = sup[i][e];
+            }
+            out[i].lnl = lnl[i]; out[i].alpha = G.alpha; out[i].tree_length = T.length(); out[i].npatterns = G.aln.npat; out[i].nsites = G.aln.nsites;
+            out[i].newick = dup_string(T.newick_labeled(G.aln.names, 10, lab, 3));
+            if (!out[i].newick) rc = ctx->c.fail(PML_ENOMEM, "host allocation failed");
+        }
+    } catch (const std::bad_alloc &) { rc = ctx->c.fail(PML_ENOMEM, "host allocation failed"); }
+    catch (const std::exception &e) { rc = ctx->c.fail(PML_EINVAL, e.what()); }
+    b->b.destroy(); delete b;
+    for (int i = 0; i < n; ++i) out[i].status = rc;
+    return rc;
+}
+int pml_sh_support(pml_ctx *ctx, const pml_alignment *aln, const char *newick, const pml_model *model, int nboot, unsigned long long seed, pml_result *out) {
+    return pml_sh_support_batch(ctx, 1, aln, &newick, model, nboot, seed, out);
+}
+
 int pml_refine_next(const char *newick, int cutoff, int ndone, const char *const *done, char **ingroup_out, int *nnodes_out, int **mean_out) {
     if (!newick || !ingroup_out || ndone < 0 || (ndone > 0 && !done)) return PML_EINVAL;
     *ingroup_out = nullptr; if (mean_out) *mean_out = nullptr; if (nnodes_out) *nnodes_out = 0;

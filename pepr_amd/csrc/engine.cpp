@@ -216,6 +216,7 @@ void Batch::destroy() {
     if (h_scalars) hipHostFree(h_scalars);
     if (h_chain) hipHostFree(h_chain);
     if (d_lenpool) hipFree(d_lenpool);
+    if (d_site2pat) { hipFree(d_site2pat); d_site2pat = nullptr; }
     h_chain = d_chain = nullptr; d_lenpool = nullptr; chain_cap = 0;
     arena = nullptr; h_stage = d_stage = nullptr; d_frags = nullptr; d_scalars = h_scalars = nullptr;
 }
@@ -621,7 +622,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
                 nr.sumtab = G.d_sumtab[t.slot]; nr.weight = G.d_weight; nr.scl = G.d_sumscl[t.slot];
                 std::memcpy(nr.rates, G.rates, sizeof nr.rates);
                 nr.t0 = t.t0; nr.tol = newton_tol; nr.out = result; nr.mpad = mp; nr.max_iter = t.max_iter;
-                nr.t_dev0 = t.t_dev0; nr.t_dev1 = t.t_dev1;
+                nr.t_dev0 = t.t_dev0; nr.t_dev1 = t.t_dev1; nr.patlnl = t.patlnl_dev;
                 nr.sync = nsync_buf + (size_t)in * NEWTON_SYNC_DOUBLES; newton_maxm = std::max(newton_maxm, mp);
                 algo_bytes += (double)G.aln.npat * (L.bytes + R.bytes + 640);
                 in++;

@@ -155,6 +155,10 @@ struct Batch {
     int nni_round(const std::vector<char> &active, std::vector<double> &lnl, std::vector<int> &applied);
     int spr_round(const std::vector<char> &active, int radius, std::vector<double> &lnl, std::vector<int> &moves);
     int search(bool nni, int spr_radius, bool opt_alpha_flag, double eps, double *lnl);
+    // SH-like local supports (FastTree's default output; FastTreeRunner.java:67-70 without -nosupport): per gene one value
+    // per internal edge in nni_round's edge order (u ascending, slot ascending, v > u inner), plus the (u, v) pairs
+    int sh_support(int nboot, unsigned long long seed, std::vector<std::vector<double>> &support, std::vector<std::vector<std::pair<int, int>>> &edges_out);
+    int *d_site2pat = nullptr; std::vector<size_t> site2pat_off;
     // FastTree -constraints matrix (names, rows of '0' '1' '-'); start trees that violate it are rebuilt
     int set_constraints(int ncons, int ntax, const char *const *names, const char *const *rows);
 
@@ -166,7 +170,8 @@ struct Batch {
     struct Tail { int gene; Side a, b; int mode; double t0; int max_iter; int slot = 0; int after = -1;
                   int bv = -1, bq = 0; /* tree branch (node, slot) t0 comes from: plan replay */
                   double *result_dev = nullptr;               /* chained pass: where k_newton writes (else res(g, slot)) */
-                  double *t_dev0 = nullptr, *t_dev1 = nullptr; /* chained pass: d_len entries of the branch */ };
+                  double *t_dev0 = nullptr, *t_dev1 = nullptr; /* chained pass: d_len entries of the branch */
+                  double *patlnl_dev = nullptr;               /* Newton tails: per-pattern lnL at the optimised length */ };
     double *res(int g, int slot = 0) const { return h_scalars + 8 * ((size_t)g * MAXTAIL + slot); }
     Side msg(int g, int node, int toward) const;
     bool is_cherry(int g, int node, int toward) const;

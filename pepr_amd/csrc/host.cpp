@@ -434,6 +434,26 @@ bool refine_query(const char *newick, int cutoff, const std::vector<std::string>
     return true;
 }
 
+std::string Tree::newick_labeled(const std::vector<std::string> &names, int digits, const std::vector<std::vector<double>> &lab, int label_digits) const {
+    std::string out; char buf[64];
+    std::function<void(int, int, double)> rec = [&](int v, int from, double l) {
+        if (v < ntax) out += names[v];
+        else {
+            out += '('; bool first = true;
+            for (int k = 0; k < 3; ++k) { const int w = nbr[v][k]; if (w < 0 || w == from) continue; if (!first) out += ','; first = false; rec(w, v, len[v][k]); }
+            out += ')';
+            const double c = lab[v][slot(v, from)];
+            if (c >= 0) { std::snprintf(buf, sizeof buf, "%.*f", label_digits, c); out += buf; }
+        }
+        std::snprintf(buf, sizeof buf, ":%.*f", digits, l); out += buf;
+    };
+    const int r = nbr[0][0];
+    out += '('; out += names[0]; std::snprintf(buf, sizeof buf, ":%.*f", digits, len[0][0]); out += buf;
+    for (int k = 0; k < 3; ++k) { const int w = nbr[r][k]; if (w < 0 || w == 0) continue; out += ','; rec(w, r, len[r][k]); }
+    out += ");";
+    return out;
+}
+
 int rf_distance(const Tree &a, const Tree &b) {
     const int n = a.ntax, words = (n + 63) / 64;
     auto splits = [&](const Tree &t) {

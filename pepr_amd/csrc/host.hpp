@@ -42,6 +42,8 @@ struct Tree {
     // labels[v] (v >= ntax) is printed after the ')' of inner node v when >= 0 (support values);
     // the label belongs to the branch between v and its parent in the printed orientation
     std::string newick_labeled(const std::vector<std::string> &names, int digits, const std::vector<std::vector<int>> &edge_label) const;
+    // same with real-valued labels printed with label_digits decimals (FastTree's 0-1 supports); < 0 = no label
+    std::string newick_labeled(const std::vector<std::string> &names, int digits, const std::vector<std::vector<double>> &edge_label, int label_digits) const;
 };
 
 int rf_distance(const Tree &a, const Tree &b);    // (|A|+|B|-2|A&B|)/2 over non-trivial splits

@@ -93,6 +93,7 @@ struct NewtonReq {          // Newton-Raphson on one branch from its sumtable
     double *out;            // out[0]=t, out[1]=lnL, out[2]=d1, out[3]=d2 (at returned t)
     double *sync;           // NEWTON_SYNC_DOUBLES zeroed doubles: arrival counter + per-workgroup partial sums
     double *t_dev0, *t_dev1; // optional: device-resident copies of the branch length (both directions) for chaining
+    double *patlnl;         // optional: per-pattern lnL (scaling applied) at the returned length, [mpad] (SH-like supports)
     int mpad;
     int max_iter;           // 0: derivatives at t0 only
 };
@@ -108,6 +109,13 @@ struct GatherSeg {
     int src_mpad, npat, dst_mpad, dst_off, ntax_dst, pad;
 };
 void launch_gather(const GatherSeg *segs, int nsegs, int max_npat, hipStream_t s);
+
+// SH-like local support of one split (FastTree's SHSupport; Guindon et al. 2010): per-pattern lnL of the current
+// arrangement (l0) and of its two NNI alternatives (l1, l2); nboot resamples of nsites alignment columns drawn with
+// the counter hash col(r, j) = mix64((seed+1)*0x9E3779B97F4A7C15 + r*nsites + j) % nsites; a resample supports the
+// split when the centred advantage of its best arrangement is smaller than the observed advantage of l0
+struct ShReq { const double *l0, *l1, *l2; const int *site2pat; double *out; unsigned long long seed; int nsites, nboot; };
+void launch_sh(const ShReq *reqs, int n, hipStream_t s);
 
 void launch_pmat(const ModelDev *model, const PmatReq *reqs, double *frags, int n, hipStream_t s);
 // constant fragment sets for the eigen-basis transforms used by the sumtable:

@@ -621,6 +621,28 @@ __global__ __launch_bounds__(256, 3) void k_newton(const ModelDev *__restrict__ 
         r.out[0] = t; r.out[1] = L; r.out[2] = d1; r.out[3] = d2;
         if (r.t_dev0) { *r.t_dev0 = t; *r.t_dev1 = t; }
     }
+    if (r.patlnl != nullptr) {                  // per-pattern lnL at the returned length (every slice its own patterns)
+        __syncthreads();
+        if (tid < NCAT * NS) { const double lr = md->eval[tid % NS] * r.rates[tid / NS]; exl[tid][0] = exp(lr * t); exl[tid][1] = lr; }
+        __syncthreads();
+        if (REG) {
+            double f = 0.0;
+#pragma unroll
+            for (int i = 0; i < CLV_ROWS / 2; ++i) f += xr[i] * exl[rhalf * (CLV_ROWS / 2) + i][0];
+            f += lane_swap1(f);
+            const int p = p_begin + (tid >> 1);
+            if (rhalf == 0 && p < p_end) r.patlnl[p] = (rw != 0.0) ? log(f * 0.25) - rscl * LOG_2_256 : 0.0;
+        } else {
+            for (int p = p_begin + tid; p < p_end; p += 256) {
+                double f = 0.0;
+                if (r.weight[p] != 0.0) {
+                    for (int row = 0; row < CLV_ROWS; ++row) f += r.sumtab[(size_t)row * M + p] * exl[row][0];
+                    f = log(f * 0.25) - r.scl[p] * LOG_2_256;
+                }
+                r.patlnl[p] = f;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -639,8 +661,50 @@ __global__ __launch_bounds__(256) void k_gather(const GatherSeg *__restrict__ se
 }
 
 // ------------------------------------------------------------------------------------------
+// k_sh: SH-like local support of one split per workgroup (see ShReq).  Thread = resamples tid, tid+256, ...;
+// the three per-pattern vectors are a few KB and stay in L1/L2.  Integer hash + gathers: latency/ALU-bound, tiny.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+    return z;
+}
+__global__ __launch_bounds__(256) void k_sh(const ShReq *__restrict__ reqs) {
+    __shared__ double red[3][4];
+    const ShReq r = reqs[blockIdx.x];
+    const int tid = threadIdx.x;
+    double orig[3] = {0.0, 0.0, 0.0};
+    for (int j = tid; j < r.nsites; j += 256) { const int p = r.site2pat[j]; orig[0] += r.l0[p]; orig[1] += r.l1[p]; orig[2] += r.l2[p]; }
+    block_sum<3, 4>(orig, red);
+    const double delta = orig[0] - fmax(orig[1], orig[2]);
+    double cnt[1] = {0.0};
+    if (delta > 0.0) {
+        const unsigned long long base = (r.seed + 1ull) * 0x9E3779B97F4A7C15ull, ns = (unsigned long long)r.nsites;
+        for (int b = tid; b < r.nboot; b += 256) {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+            const unsigned long long k0 = base + (unsigned long long)b * ns;
+            for (int j = 0; j < r.nsites; ++j) {
+                const int p = r.site2pat[(int)(mix64(k0 + (unsigned long long)j) % ns)];
+                s0 += r.l0[p]; s1 += r.l1[p]; s2 += r.l2[p];
+            }
+            s0 -= orig[0]; s1 -= orig[1]; s2 -= orig[2];            // centred
+            const double best = fmax(s0, fmax(s1, s2));
+            // advantage of the best arrangement over the better of the other two
+            const double second = (best == s0) ? fmax(s1, s2) : (best == s1 ? fmax(s0, s2) : fmax(s0, s1));
+            if (best - second < delta) cnt[0] += 1.0;
+        }
+    }
+    __shared__ double red1[1][4];
+    block_sum<1, 4>(cnt, red1);
+    if (tid == 0) *r.out = (r.nboot > 0) ? cnt[0] / (double)r.nboot : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+void launch_sh(const ShReq *reqs, int n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_sh, dim3((unsigned)n), dim3(256), 0, s, reqs);
+}
 void launch_gather(const GatherSeg *segs, int nsegs, int max_npat, hipStream_t s) {
     if (nsegs <= 0 || max_npat <= 0) return;
     hipLaunchKernelGGL(k_gather, dim3((unsigned)nsegs, (unsigned)((max_npat + 255) / 256)), dim3(256), 0, s, segs);

@@ -20,6 +20,10 @@
 
 #include "engine.hpp"
 
+#define HIPCHK(expr)                                                                          \
+    do { hipError_t e_ = (expr);                                                              \
+         if (e_ != hipSuccess) return ctx->fail(-4, std::string("HIP: ") + hipGetErrorString(e_)); } while (0)
+
 namespace pml {
 
 namespace {
@@ -81,6 +85,74 @@ int Batch::light_smooth(const std::vector<char> &active, double *lnl) {
         for (size_t g = 0; g < sm.size(); ++g) if (sm[g] && md[g] < 1e-3) sm[g] = 0;
     }
     return evaluate(active, lnl);
+}
+
+// SH-like local supports: for every internal edge the current arrangement and its two NNI alternatives are scored as
+// in nni_round (central branch Newton-optimised, nothing else re-optimised -- FastTree does not re-optimise for the
+// resamples either), k_newton also leaves the per-pattern lnL of each arrangement in d_patlnl[0..2], and k_sh resamples
+// the alignment columns nboot times on the device.  One run() + one k_sh launch per edge for the whole batch.
+int Batch::sh_support(int nboot, unsigned long long seed, std::vector<std::vector<double>> &support, std::vector<std::vector<std::pair<int, int>>> &edges) {
+    const int n = (int)genes.size();
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!d_site2pat) {
+        size_t tot = 0; site2pat_off.assign(n, 0);
+        for (int g = 0; g < n; ++g) {
+            if ((int)genes[g].aln.site2pat.size() != genes[g].aln.nsites) return ctx->fail(-1, "SH-like supports need the site map (not available for device-gathered replicates)");
+            site2pat_off[g] = tot; tot += (size_t)genes[g].aln.nsites;
+        }
+        HIPCHK(hipMalloc((void **)&d_site2pat, std::max<size_t>(tot, 1) * sizeof(int)));
+        for (int g = 0; g < n; ++g) HIPCHK(hipMemcpy(d_site2pat + site2pat_off[g], genes[g].aln.site2pat.data(), (size_t)genes[g].aln.nsites * sizeof(int), hipMemcpyHostToDevice));
+    }
+    std::vector<double> l0(n);
+    if (int rc = evaluate(std::vector<char>(n, 1), l0.data())) return rc;       // every cached CLV valid
+    edges.assign(n, {}); support.assign(n, {});
+    size_t maxsteps = 0;
+    for (int g = 0; g < n; ++g) {
+        const Tree &T = genes[g].tree; const int nt = T.ntax;
+        for (int u = nt; u < T.nnodes(); ++u) for (int k = 0; k < 3; ++k) { const int v = T.nbr[u][k]; if (v < nt || v < u) continue; edges[g].push_back({u, v}); }
+        support[g].assign(edges[g].size(), 0.0);
+        maxsteps = std::max(maxsteps, edges[g].size());
+    }
+    ShReq *d_req = nullptr; double *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_req, sizeof(ShReq) * n));
+    if (hipMalloc((void **)&d_out, sizeof(double) * n) != hipSuccess) { hipFree(d_req); return ctx->fail(-4, "allocation failed"); }
+    struct Drop { ShReq *a; double *b; ~Drop() { hipFree(a); hipFree(b); } } drop{d_req, d_out};
+    std::vector<ShReq> hreq(n); std::vector<double> hout(n); std::vector<int> who;
+    for (size_t step = 0; step < maxsteps; ++step) {
+        std::vector<PendingOp> ops; std::vector<Tail> tails;
+        who.clear();
+        for (int g = 0; g < n; ++g) {
+            if (step >= edges[g].size()) continue;
+            Gene &G = genes[g]; const Tree &T = G.tree;
+            auto [u, v] = edges[g][step];
+            const double t0 = T.len[u][T.slot(u, v)];
+            int a[2], c[2]; double la[2], lc[2];
+            others(T, u, v, a, la); others(T, v, u, c, lc);
+            need(g, u, v, ops); need(g, v, u, ops);
+            need(g, a[0], u, ops); need(g, a[1], u, ops); need(g, c[0], v, ops); need(g, c[1], v, ops);
+            Tail t0t{g, msg(g, u, v), msg(g, v, u), MODE_SUMTABLE, t0, 32, 0, -1}; t0t.patlnl_dev = G.d_patlnl[0];
+            tails.push_back(t0t);
+            for (int alt = 1; alt <= 2; ++alt) {
+                const int y = (alt == 1) ? 0 : 1, sx = 2 * alt - 2, sy = 2 * alt - 1;
+                PendingOp X; X.gene = g; X.out_kind = SIDE_SCRATCH; X.out_id = sx; X.level = 0;
+                X.child[0] = msg(g, a[0], u); X.t[0] = la[0]; X.child[1] = msg(g, c[y], v); X.t[1] = lc[y];
+                PendingOp Y; Y.gene = g; Y.out_kind = SIDE_SCRATCH; Y.out_id = sy; Y.level = 0;
+                Y.child[0] = msg(g, a[1], u); Y.t[0] = la[1]; Y.child[1] = msg(g, c[1 - y], v); Y.t[1] = lc[1 - y];
+                ops.push_back(X); ops.push_back(Y);
+                Tail ta{g, {SIDE_SCRATCH, sx}, {SIDE_SCRATCH, sy}, MODE_SUMTABLE, t0, 32, alt, -1}; ta.patlnl_dev = G.d_patlnl[alt];
+                tails.push_back(ta);
+            }
+            hreq[who.size()] = ShReq{G.d_patlnl[0], G.d_patlnl[1], G.d_patlnl[2], d_site2pat + site2pat_off[g], d_out + who.size(), seed, G.aln.nsites, nboot};
+            who.push_back(g);
+        }
+        if (int rc = run(ops, tails)) return rc;
+        HIPCHK(hipMemcpyAsync(d_req, hreq.data(), sizeof(ShReq) * who.size(), hipMemcpyHostToDevice, ctx->stream));
+        launch_sh(d_req, (int)who.size(), ctx->stream);
+        HIPCHK(hipMemcpyAsync(hout.data(), d_out, sizeof(double) * who.size(), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < who.size(); ++i) support[who[i]][step] = hout[i];
+    }
+    return 0;
 }
 
 int Batch::nni_round(const std::vector<char> &active, std::vector<double> &lnl, std::vector<int> &applied) {

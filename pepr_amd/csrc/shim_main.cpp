@@ -4,6 +4,7 @@
 // Built twice: -DSHIM_FASTTREE -> bin/FastTree_WAG, -DSHIM_RAXML -> bin/raxmlHPC (+ -PTHREADS).
 // Accepts exactly the argv subsets PEPR emits:
 //   FastTree_WAG -gamma [-nosupport] [-constraints <c.faa>] <aln.faa>   FastTreeRunner.java:67-86
+//     (without -nosupport the tree carries SH-like local supports, 0-1, 3 decimals; -seed / -boot as FastTree)
 //   raxmlHPC -f d|e|g -m PROTGAMMAWAG -s <aln.phy> -n <run> [-t tree] [-z trees] [-T n] [-p seed]
 //                                                                   RAxMLRunner.java:115-132,196-208,253-272
 // Everything numeric happens in libpeprml.so (HIP); these files only parse and print.
@@ -76,11 +77,14 @@ static int fail(const char *tool, const std::string &msg) { std::fprintf(stderr,
 #ifdef SHIM_FASTTREE
 int main(int argc, char **argv) {
     const char *tool = "FastTree_WAG";
-    const char *file = nullptr, *cons_file = nullptr; bool gamma = false;
+    const char *file = nullptr, *cons_file = nullptr; bool gamma = false, nosupport = false; unsigned long long sh_seed = 314159; int nboot = 1000;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "-gamma") gamma = true;
-        else if (a == "-nosupport" || a == "-quiet" || a == "-nopr") {}
+        else if (a == "-nosupport") nosupport = true;
+        else if (a == "-quiet" || a == "-nopr") {}
+        else if (a == "-seed" && i + 1 < argc) sh_seed = std::strtoull(argv[++i], nullptr, 10);
+        else if (a == "-boot" && i + 1 < argc) nboot = std::atoi(argv[++i]);
         else if (a == "-gtr" || a == "-nt") return fail(tool, "nucleotide models are not built (PEPR never requests them)");
         else if (a == "-constraints" && i + 1 < argc) cons_file = argv[++i];
         else if (a == "-log" && i + 1 < argc) ++i;
@@ -109,7 +113,14 @@ int main(int argc, char **argv) {
     if (rc) { std::string m = pml_last_error(ctx); pml_destroy(ctx); return fail(tool, m); }
     std::fprintf(stderr, "FastTree_WAG (peprml, MI355X): %d seqs, %d positions, %d patterns\nGamma(4) LogLk = %.3f alpha = %.3f\n",
                  v.ntax, v.nsites, res.npatterns, res.lnl, res.alpha);
-    std::printf("%s\n", reformat(res.newick, 5, false).c_str());
+    if (!nosupport && nboot > 0 && v.ntax > 3) {         // FastTree's default: SH-like local supports (0-1) as inner labels
+        pml_model m2 = {4, res.alpha, PML_PI_WAG_FULL};
+        pml_result sup;
+        const int rc2 = pml_sh_support(ctx, &v, res.newick, &m2, nboot, sh_seed, &sup);
+        if (rc2) { std::string m = pml_last_error(ctx); pml_result_free(&res); pml_destroy(ctx); return fail(tool, m); }
+        std::printf("%s\n", reformat(sup.newick, 5, false).c_str());
+        pml_result_free(&sup);
+    } else std::printf("%s\n", reformat(res.newick, 5, false).c_str());
     pml_result_free(&res); pml_destroy(ctx);
     return 0;
 }

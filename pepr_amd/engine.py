@@ -152,6 +152,10 @@ class Context:
         o = _opts(optimize_alpha, nni, spr_radius, epsilon, constraints=constraints)
         return self._oneshot(self.L.pml_search_batch, genes, start_newicks, _model(ncat, alpha, pi_mode), (C.byref(o),))
 
+    def sh_support(self, genes, newicks, alpha=1.0, ncat=4, pi_mode=PI_RAXML_3DP, nboot=1000, seed=314159):
+        """FastTree's SH-like local supports for given trees: list of dicts, "newick" carries 0-1 labels (3 decimals)."""
+        return self._oneshot(self.L.pml_sh_support_batch, genes, newicks, _model(ncat, alpha, pi_mode), (int(nboot), int(seed)))
+
     def bootstrap(self, gene, reps=100, seed=1, spr_radius=5, epsilon=1e-3, alpha=1.0, ncat=4, pi_mode=PI_RAXML_3DP):
         """`raxmlHPC -f a -x seed -N reps`: best ML tree with percent supports + the replicate trees."""
         keep = []

@@ -12,7 +12,7 @@ Behaviour kept from the reference: a failed build leaves the result `None` (Fast
 125-131 logs and continues; callers see a null tree string); the ML matrix is a RAxML model
 string (default PROTGAMMAWAG, PhylogenomicPipeline2.java:248-250); threads/processes are accepted
 and ignored (the GPU engine needs no -T).  Not mirrored (out of scope): parsimony
-bootstrap (-Y), nucleotide (-gtr -nt), FastTree's SH-like local supports (bootstrapReps > 0 there).
+bootstrap (-Y), nucleotide (-gtr -nt).
 """
 import logging
 
@@ -218,6 +218,9 @@ class FastTreeRunner:
             r = ctx.search([self.alignment.as_gene()], None, nni=True, spr_radius=0, pi_mode=engine.PI_WAG_FULL,
                            constraints=self._constraint_matrix())[0]
             self.result, self.lnl = r["newick"], r["lnl"]
+            if self.bootstrapReps > 0 and len(self.alignment.getTaxa()) > 3:   # FastTreeRunner.java:67-70: no -nosupport -> SH-like supports
+                s = ctx.sh_support([self.alignment.as_gene()], [r["newick"]], alpha=r["alpha"], pi_mode=engine.PI_WAG_FULL)[0]
+                self.result = s["newick"]
         except Exception as e:
             log.error("FastTreeRunner failed: %s", e)
             self.result = None
