@@ -757,7 +757,7 @@ static double eng_opt_alpha(po_engine *e, po_tree *t, double tol) {
         const double lo = a, hi = b;
         double w = x, v = x, fw = fx, fv = fx, d = 0, ee = 0;
         for (int it = 0; it < 60; it++) {
-            double xm = 0.5 * (a + b), tol1 = tol * fabs(x) + 1e-6, tol2 = 2 * tol1;
+            double xm = 0.5 * (a + b), tol1 = tol, tol2 = 2 * tol1;      /* absolute in log(alpha) = relative in alpha */
             if (fabs(x - xm) <= tol2 - 0.5 * (b - a)) break;
             int golden = 1; double u;
             if (fabs(ee) > tol1) {
@@ -774,7 +774,7 @@ static double eng_opt_alpha(po_engine *e, po_tree *t, double tol) {
             if (fu <= fx) { if (u >= x) a = x; else b = x; v = w; fv = fw; w = x; fw = fx; x = u; fx = fu; }
             else { if (u < x) a = u; else b = u; if (fu <= fw || w == x) { v = w; fv = fw; w = u; fw = fu; } else if (fu <= fv || v == x || v == w) { v = u; fv = fu; } }
         }
-        const double edge = 4 * (tol * fabs(x) + 1e-6);
+        const double edge = 4 * tol;
         if ((x - lo < edge && lo > LMIN) || (hi - x < edge && hi < LMAX)) { W *= 2; continue; }
         break;
     }

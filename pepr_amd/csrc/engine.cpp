@@ -959,7 +959,7 @@ int Batch::opt_alpha(const std::vector<char> &active, double *lnl, double tol) {
             if (!act[g]) continue;
             for (;;) {
                 if (br[g].propose()) { set_alpha(g, std::exp(br[g].u)); any = true; break; }
-                const double x = br[g].x, edge = 4 * (tol * std::fabs(x) + 1e-6);
+                const double x = br[g].x, edge = 4 * tol;
                 if (++win[g] < 8 && ((x - lo[g] < edge && lo[g] > LMIN) || (hi[g] - x < edge && hi[g] < LMAX))) { W[g] *= 2; open_window(g, x, br[g].fx); continue; }
                 act[g] = 0; break;
             }

@@ -627,7 +627,7 @@ void Brent::start(double lo, double hi, double x0, double fx0, double tol_) {
 bool Brent::propose() {
     const double gold = 0.3819660112501051;
     if (done || iter >= 60) { done = true; return false; }
-    const double xm = 0.5 * (a + b), tol1 = tol * std::fabs(x) + 1e-6, tol2 = 2 * tol1;
+    const double xm = 0.5 * (a + b), tol1 = tol, tol2 = 2 * tol1;      // absolute in log(alpha) = relative in alpha
     if (std::fabs(x - xm) <= tol2 - 0.5 * (b - a)) { done = true; return false; }
     bool golden = true;
     if (std::fabs(e) > tol1) {
