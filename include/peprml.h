@@ -83,7 +83,8 @@ typedef struct {
     int nni;                 /* 1: NNI hill climbing */
     int spr_radius;          /* >0: SPR rounds with this rearrangement radius */
     double epsilon;          /* stop when a round gains less than this many lnL units */
-    unsigned seed;           /* reserved (search is deterministic) */
+    unsigned seed;           /* 0: NJ start tree (deterministic); != 0: randomised stepwise-addition parsimony start with
+                              * this seed, as `raxmlHPC -f d -p seed` starts (genes that come with a start tree keep it) */
     /* topological constraints, FastTree's -constraints semantics as PEPR produces them
      * (FastTreeRunner.getFastTreeConstraintsForTree, FastTreeRunner.java:243-273): a 0/1/- matrix,
      * one row per named taxon, one column per constrained split ('-' = taxon free in that column).

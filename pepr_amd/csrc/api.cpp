@@ -184,6 +184,23 @@ static size_t gene_bytes_bound(const pml_alignment &a, bool score_only) {
 static int oneshot_chunk(pml_ctx *ctx, int op, int n, const pml_alignment *alns, const char *const *newicks,
                          const pml_model *model, const pml_search_opts *opts, int flags, pml_result *out) {
     pml_batch *b = nullptr;
+    // RAxML starts `-f d` from a randomised stepwise-addition parsimony tree (-p seed): opts->seed != 0 asks for
+    // that start for every gene without a given start tree (seed 0 = the deterministic NJ start)
+    std::vector<std::string> pstart; std::vector<const char *> pnw;
+    if (op == OP_SEARCH && opts && opts->seed != 0) {
+        std::vector<int> idx;
+        for (int i = 0; i < n; ++i) if (!newicks || !newicks[i]) idx.push_back(i);
+        if (!idx.empty()) {
+            std::vector<pml_alignment_view> views;
+            for (int i : idx) views.push_back(pml_alignment_view{alns[i].ntax, alns[i].nsites, alns[i].names, alns[i].rows});
+            std::vector<Tree> trees; std::vector<EncodedAlignment> enc; std::vector<long long> len; std::vector<int> moves;
+            if (int prc = parsimony_batch(&ctx->c, (int)idx.size(), views.data(), opts->seed, 20, trees, enc, len, moves)) return prc;
+            pstart.resize(n); pnw.assign(n, nullptr);
+            for (int i = 0; i < n; ++i) if (newicks && newicks[i]) pnw[i] = newicks[i];
+            for (size_t k = 0; k < idx.size(); ++k) { pstart[idx[k]] = trees[k].newick(enc[k].names, 6); pnw[idx[k]] = pstart[idx[k]].c_str(); }
+            newicks = pnw.data();
+        }
+    }
     int rc = batch_create_impl(ctx, n, alns, newicks, model, op == OP_SCORE, &b);
     if (rc) return rc;
     std::vector<double> lnl(n);
@@ -263,7 +280,7 @@ struct pml_request {
 static bool compatible(const pml_request &a, const pml_request &b) {
     return a.op == b.op && a.flags == b.flags && a.model.ncat == b.model.ncat && a.model.alpha == b.model.alpha &&
            a.model.pi_mode == b.model.pi_mode && a.opts.optimize_alpha == b.opts.optimize_alpha && a.opts.nni == b.opts.nni &&
-           a.opts.spr_radius == b.opts.spr_radius && a.opts.epsilon == b.opts.epsilon;
+           a.opts.spr_radius == b.opts.spr_radius && a.opts.epsilon == b.opts.epsilon && a.opts.seed == b.opts.seed;
 }
 static void run_group(pml_ctx *ctx, std::vector<pml_request *> &grp) {
     const int n = (int)grp.size();

@@ -185,7 +185,7 @@ int main(int argc, char **argv) {
             pml_result_free(&res);
         }
     } else if (f == "d") {
-        pml_search_opts opts = {1, 1, 5, 1e-3, 0};          // NNI + lazy SPR radius 5 ("best rearrangement setting 5")
+        pml_search_opts opts = {1, 1, 5, 1e-3, seed};       // parsimony start (-p seed), NNI + lazy SPR radius 5 ("best rearrangement setting 5")
         pml_result res;
         rc = pml_search(ctx, &v, nullptr, &model, &opts, &res);
         if (!rc) {

@@ -148,8 +148,9 @@ class Context:
         return self._oneshot(self.L.pml_optimize_batch, genes, newicks, _model(ncat, alpha, pi_mode), (C.byref(o),))
 
     def search(self, genes, start_newicks=None, alpha=1.0, ncat=4, pi_mode=PI_RAXML_3DP, optimize_alpha=True,
-               nni=True, spr_radius=0, epsilon=1e-3, constraints=None):
-        o = _opts(optimize_alpha, nni, spr_radius, epsilon, constraints=constraints)
+               nni=True, spr_radius=0, epsilon=1e-3, constraints=None, seed=0):
+        """seed != 0: RAxML-style randomised stepwise-addition parsimony start trees instead of NJ."""
+        o = _opts(optimize_alpha, nni, spr_radius, epsilon, seed=seed, constraints=constraints)
         return self._oneshot(self.L.pml_search_batch, genes, start_newicks, _model(ncat, alpha, pi_mode), (C.byref(o),))
 
     def sh_support(self, genes, newicks, alpha=1.0, ncat=4, pi_mode=PI_RAXML_3DP, nboot=1000, seed=314159):

@@ -137,7 +137,7 @@ class RAxMLRunner:
                 self.bestTreeWithSupports, self.lnl, self.alpha = r["newick"], r["lnl"], r["alpha"]
                 self.bestTree = None                                              # -f a writes no RAxML_result
                 return
-            r = ctx.search([gene], None, spr_radius=self.spr_radius, **mdl)[0]
+            r = ctx.search([gene], None, spr_radius=self.spr_radius, seed=self.seed, **mdl)[0]      # parsimony start, as -f d
             self.bestTree, self.lnl, self.alpha = r["newick"], r["lnl"], r["alpha"]
         except Exception as e:          # reference: rc logged, result stays null
             log.error("RAxMLRunner failed: %s", e)

@@ -84,3 +84,17 @@ def test_parsimony_bl_builder_and_shim(gpu_ctx, tmp_path):
     assert r.returncode == 0, r.stderr
     bl = open(tmp_path / "RAxML_result.r1BL").read().strip()
     assert engine.rf_distance(mp, bl) == 0 and engine.rf_distance(mp, t_mp) == 0
+
+
+def test_search_from_parsimony_start_vs_oracle(gpu_ctx):
+    """`raxmlHPC -f d -p seed` starts from a randomised stepwise-addition parsimony tree: pml_search_opts.seed != 0.
+    Same start tree on both sides (integer work), then the usual search parity (RF 0, |dlnL| < 1e-3)."""
+    names, rows, nw = synth.simulate_alignment(16, 300, 5100)
+    g = gpu_ctx.search([(names, rows)], None, nni=True, spr_radius=5, seed=4242)[0]
+    aln = po.Alignment(names, rows)
+    start, _, _ = po.parsimony_tree(aln, 4242, 20)
+    e = po.Engine(aln, po.Model(0), 4, 1.0)
+    lnl, tree = e.search(start, 5, 1e-3)
+    assert util.rf_collapsed(g["newick"], tree.newick(12)) == 0 and abs(g["lnl"] - lnl) < 1e-3
+    nj = gpu_ctx.search([(names, rows)], None, nni=True, spr_radius=5)[0]
+    assert abs(nj["lnl"] - g["lnl"]) < 5.0          # two starts, one likelihood surface: same neighbourhood

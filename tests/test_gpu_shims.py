@@ -67,7 +67,7 @@ def test_raxml_shim_modes(tmp_path, gpu_ctx):
     for f in ("RAxML_result.d1", "RAxML_bestTree.d1", "RAxML_info.d1", "RAxML_log.d1"):
         assert (tmp_path / f).exists()
     best = (tmp_path / "RAxML_result.d1").read_text().strip()
-    sref = gpu_ctx.search([(names, rows)], None, nni=True, spr_radius=5)[0]
+    sref = gpu_ctx.search([(names, rows)], None, nni=True, spr_radius=5, seed=12345)[0]      # parsimony start, default -p
     assert engine.rf_distance(best, sref["newick"]) == 0
     # same run name again is refused
     assert run(["-f", "d", "-m", "PROTGAMMAWAG", "-s", "g.phy", "-n", "d1"]).returncode != 0
