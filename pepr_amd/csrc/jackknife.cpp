@@ -111,25 +111,42 @@ extern "C" int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *gene
             main_tree = b.genes[0].tree; main_names = b.genes[0].aln.names; main_alpha = b.genes[0].alpha; main_npat = b.genes[0].aln.npat; main_nsites = b.genes[0].aln.nsites;
             b.destroy();
         }
-        // support trees: one batch
+        // support trees: one device batch, or consecutive sub-batches when the replicates' CLV arenas do not fit in free
+        // HBM together (a replicate of 100 taxa x 10^5 patterns needs ~19 GB in search mode)
         std::vector<Tree> sup((size_t)reps_here);
         std::string sup_txt;
         if (reps_here > 0) {
-            Batch b; int rc = b.create_replicates(&ctx->c, store, rep, pm, ncat, alpha);
-            std::vector<double> l(reps_here);
-            if (!rc) rc = b.search(true, 0, true, eps, l.data());
-            if (rc) { b.destroy(); return rc; }
-            for (int r = 0; r < reps_here; ++r) {
-                const Gene &G = b.genes[r];
-                const std::string nw = G.tree.newick(G.aln.names, 6);
-                sup_txt += nw; sup_txt += '\n';
-                // a replicate may lack taxa that occur only in unselected genes: such trees cannot
-                // contain the main tree's bipartitions and are counted as not supporting
-                if (srank != 0) continue;
-                if (G.aln.names == main_names) sup[r] = G.tree;
-                else { std::string e2; Tree t; if (Tree::parse(nw.c_str(), main_names, t, e2)) sup[r] = t; else sup[r] = Tree(); }
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)1 << 40;
+            size_t budget = (size_t)(0.85 * (double)(free_b + ctx->c.arena_cache_bytes));
+            if (const char *e = std::getenv("PML_HBM_BUDGET_MB")) budget = (size_t)std::atoll(e) << 20;   // test hook
+            auto rep_bytes = [&](const std::vector<int> &sel) {
+                size_t pats = 0; std::set<std::string> taxa;
+                for (int g : sel) { pats += (size_t)store.items[g].aln.npat; taxa.insert(store.items[g].aln.names.begin(), store.items[g].aln.names.end()); }
+                const size_t mp = (pats + 31) / 32 * 32, nt = std::max<size_t>(taxa.size(), 3), slots = 3 * (nt - 2) + NSCRATCH + MAXTAIL;
+                return slots * CLV_ROWS * mp * 8 + slots * mp * 4 + nt * mp + 64 * mp + (1 << 16);
+            };
+            for (int begin = 0; begin < reps_here;) {
+                size_t used = 0; int end = begin;
+                while (end < reps_here) { const size_t need = rep_bytes(rep[end]); if (end > begin && used + need > budget) break; used += need; ++end; }
+                std::vector<std::vector<int>> part(rep.begin() + begin, rep.begin() + end);
+                Batch b; int rc = b.create_replicates(&ctx->c, store, part, pm, ncat, alpha);
+                std::vector<double> l(end - begin);
+                if (!rc) rc = b.search(true, 0, true, eps, l.data());
+                if (rc) { b.destroy(); return rc; }
+                for (int r = begin; r < end; ++r) {
+                    const Gene &G = b.genes[r - begin];
+                    const std::string nw = G.tree.newick(G.aln.names, 6);
+                    sup_txt += nw; sup_txt += '\n';
+                    // a replicate may lack taxa that occur only in unselected genes: such trees cannot
+                    // contain the main tree's bipartitions and are counted as not supporting
+                    if (srank != 0) continue;
+                    if (G.aln.names == main_names) sup[r] = G.tree;
+                    else { std::string e2; Tree t; if (Tree::parse(nw.c_str(), main_names, t, e2)) sup[r] = t; else sup[r] = Tree(); }
+                }
+                b.destroy();
+                begin = end;
             }
-            b.destroy();
         }
         std::vector<Tree> usable;
         for (auto &t : sup) if (t.ntax == main_tree.ntax) usable.push_back(t);
@@ -181,12 +198,23 @@ extern "C" int pml_bootstrap(pml_ctx *ctx, const pml_alignment *aln, const pml_m
             std::vector<std::vector<const char *>> rps((size_t)reps);
             std::vector<pml_alignment_view> vs((size_t)reps);
             for (int r = 0; r < reps; ++r) { for (auto &x : rows[r]) rps[r].push_back(x.c_str()); vs[r] = pml_alignment_view{n, L, aln->names, rps[r].data()}; }
-            Batch b; int rc = b.create(&ctx->c, reps, vs.data(), nullptr, pm, ncat, alpha, false);
-            std::vector<double> l((size_t)reps);
-            if (!rc) rc = b.search(true, 0, true, eps, l.data());
-            if (rc) { b.destroy(); return rc; }
-            for (int r = 0; r < reps; ++r) { trees[r] = b.genes[r].tree; txt += b.genes[r].tree.newick(names, 6); txt += '\n'; }
-            b.destroy();
+            // one device batch, or consecutive sub-batches when the replicates do not fit in free HBM together
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)1 << 40;
+            size_t budget = (size_t)(0.85 * (double)(free_b + ctx->c.arena_cache_bytes));
+            if (const char *e = std::getenv("PML_HBM_BUDGET_MB")) budget = (size_t)std::atoll(e) << 20;   // test hook
+            const size_t mp = ((size_t)L + 31) / 32 * 32, slots = 3 * ((size_t)n - 2) + NSCRATCH + MAXTAIL;
+            const size_t per_rep = slots * CLV_ROWS * mp * 8 + slots * mp * 4 + (size_t)n * mp + 64 * mp + (1 << 16);
+            const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)reps, budget / per_rep));
+            for (int begin = 0; begin < reps; begin += chunk) {
+                const int m = std::min(chunk, reps - begin);
+                Batch b; int rc = b.create(&ctx->c, m, vs.data() + begin, nullptr, pm, ncat, alpha, false);
+                std::vector<double> l((size_t)m);
+                if (!rc) rc = b.search(true, 0, true, eps, l.data());
+                if (rc) { b.destroy(); return rc; }
+                for (int r = 0; r < m; ++r) { trees[begin + r] = b.genes[r].tree; txt += b.genes[r].tree.newick(names, 6); txt += '\n'; }
+                b.destroy();
+            }
         }
         auto counts = support_counts(best, trees);
         if (reps > 0) for (auto &row : counts) for (int &c : row) if (c >= 0) c = (int)(0.5 + 100.0 * c / reps);   // percent, as RAxML_bipartitions

@@ -73,3 +73,12 @@ def test_jackknife_sharded_equals_unsharded(gpu_ctx):
     decorated = engine.support_tree(plain, merged, digits=6)
     assert sorted(re.findall(r"\)(\d+):", decorated)) == sorted(re.findall(r"\)(\d+):", whole["newick"]))
     assert engine.rf_distance(decorated, whole["newick"]) == 0
+
+
+def test_jackknife_replicate_sub_batching(gpu_ctx, monkeypatch):
+    """replicates whose arenas do not fit in HBM together run as consecutive sub-batches: same result"""
+    names, true_nw, genes = _genes(9, 6, 90, 21)
+    whole = gpu_ctx.jackknife(genes, reps=8, seed=5, spr_radius_full=0)
+    monkeypatch.setenv("PML_HBM_BUDGET_MB", "30")
+    parts = gpu_ctx.jackknife(genes, reps=8, seed=5, spr_radius_full=0)
+    assert parts["support_trees"] == whole["support_trees"] and parts["newick"] == whole["newick"]
