@@ -10,7 +10,8 @@
  * restates their *published* algorithm: Felsenstein pruning (Felsenstein 1981) under the WAG
  * model (Whelan & Goldman 2001) with discrete-Gamma rate heterogeneity (Yang 1994, mean of
  * K equal-probability bins), Newton-Raphson branch-length optimisation, Brent alpha
- * optimisation and NNI / SPR hill climbing.
+ * optimisation and NNI / SPR hill climbing; Fitch (1971) parsimony with stepwise addition + SPR (`raxmlHPC -y`);
+ * SH-like local supports (FastTree `SHSupport`, Guindon et al. 2010).
  *
  * PARITY UNPINNED against the reference binaries: the reference holds no golden vectors or
  * tests for this path and its bundled prebuilt executables may not be
