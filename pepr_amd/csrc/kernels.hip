@@ -63,10 +63,11 @@ __global__ __launch_bounds__(256) void k_pmat(const ModelDev *__restrict__ md,
                                               double *__restrict__ frags, int n) {
     __shared__ double e[NCAT * NS];
     __shared__ double sUi[NS * NS];
-    __shared__ double sP[NCAT * NS * NS];      // tip tables only
+    __shared__ double sP[NCAT * NS * NS];      // staging of the result (fragment order) / P itself for tip tables
+    __shared__ double sU[NS * (NS + 1)];       // U rows, stride 21: read per lane row-wise without 20 strided global loads
     const int tid = threadIdx.x;
     const PmatReq req = reqs[blockIdx.x];
-    for (int i = tid; i < NS * NS; i += 256) sUi[i] = md->Uinv[i];
+    for (int i = tid; i < NS * NS; i += 256) { sUi[i] = md->Uinv[i]; sU[(i / NS) * (NS + 1) + i % NS] = md->U[i]; }
     const double tlen = req.tp ? *req.tp : req.t;
     if (tid < NCAT * NS) e[tid] = exp(md->eval[tid % NS] * (tlen * req.rates[tid / NS]));
     __syncthreads();
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void k_pmat(const ModelDev *__restrict__ md,
         const int c = row / NS, s2 = row % NS;
         double W[NS];
 #pragma unroll
-        for (int k = 0; k < NS; ++k) W[k] = md->U[s2 * NS + k] * e[c * NS + k];
+        for (int k = 0; k < NS; ++k) W[k] = sU[s2 * (NS + 1) + k] * e[c * NS + k];
         const double scale = req.kind == PM_FRAGS_PI ? md->pi[s2] : 1.0;
         for (int j = g; j < NS; j += 3) {
             double v = 0.0;
