@@ -167,6 +167,9 @@ int Batch::layout(double alpha, bool score_only) {
             return ctx->fail(-4, "device arena of " + std::to_string(total >> 20) + " MiB does not fit");
         }
     }
+    // debugging aid: a reused arena holds stale data; poisoning it (all-ones = NaN doubles, -1 counts) makes any read of
+    // a location this batch has not written show up in the results
+    if (std::getenv("PML_POISON_ARENA")) HIPCHK(hipMemsetAsync(arena, 0xFF, total, ctx->stream));
     for (int g = 0; g < n; ++g) {
         Gene &G = genes[g];
         const int nt = G.aln.ntax, mp = G.aln.mpad;
