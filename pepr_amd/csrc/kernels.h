@@ -11,9 +11,11 @@ constexpr int CLV_ROWS = NCAT * NS;    // 80 rows of `mpad` doubles: CLV[cat*20+
 constexpr int PFRAG = NCAT * 25 * 16;      // doubles per transition-matrix fragment set (12.8 KB)
 constexpr int PAT_PER_WAVE = 32;       // one MFMA chunk: 2 N-tiles of 16 patterns (16 B / lane)
 constexpr int NCODES = 23;
-// tip table: T[c][code][q][kk] (kk padded to 8) = sum_{j in code} P_c[s = 4 kk + q][j]: the five rows a lane
-// needs (its q, kk = 0..4) are 40 contiguous bytes -> 3 loads instead of 5 gathers (23.5 KB per branch)
-constexpr int TIPTAB_DOUBLES = NCAT * NCODES * 4 * 8;
+// tip table: T[c][code][q][kk] (kk padded to 6) = sum_{j in code} P_c[s = 4 kk + q][j]: the five rows a lane
+// needs (its q, kk = 0..4) are 40 contiguous bytes of a 48-byte, 16-byte-aligned record -> 3 loads instead of 5
+// gathers (17.7 KB per branch)
+constexpr int TIPTAB_KK = 6;
+constexpr int TIPTAB_DOUBLES = NCAT * NCODES * 4 * TIPTAB_KK;
 constexpr int FRAG_STRIDE = TIPTAB_DOUBLES;          // doubles per k_pmat output slot (fragment set or tip table)
 
 // device-resident model constants (one per ctx)

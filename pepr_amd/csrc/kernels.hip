@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_pmat(const ModelDev *__restrict__ md,
         return;
     }
     for (int idx = tid; idx < TIPTAB_DOUBLES; idx += 256) {
-        const int kk = idx & 7, q = (idx >> 3) & 3, code = (idx >> 5) % NCODES, c = (idx >> 5) / NCODES;
+        const int kk = idx % TIPTAB_KK, rec = idx / TIPTAB_KK, q = rec & 3, code = (rec >> 2) % NCODES, c = (rec >> 2) / NCODES;
         double v = 0.0;
         if (kk < 5) {
             const double *prow = sP + (c * NS + 4 * kk + q) * NS;
@@ -203,10 +203,10 @@ __device__ __forceinline__ void contract_stream(const double *__restrict__ frag_
 }
 
 // cherry operand: product of the two tips' table rows (tables live in global memory, L2-resident:
-// every workgroup of the gene reads the same 2 x 23.5 KB); a lane's five rows are 40 contiguous bytes
+// every workgroup of the gene reads the same 2 x 17.7 KB); a lane's five rows are 40 contiguous bytes
 struct Rows5 { dvec2 a, b; double c; };
 __device__ __forceinline__ Rows5 load_rows(const double *tab, unsigned code, int c, int q) {
-    gcptr p = (gcptr)tab + ((size_t)((c * NCODES + code) * 4 + q) << 6);
+    gcptr p = (gcptr)tab + (size_t)((c * NCODES + code) * 4 + q) * (TIPTAB_KK * 8);
     Rows5 r;
     r.a = *reinterpret_cast<const GLOBAL_AS dvec2 *>(p);
     r.b = *reinterpret_cast<const GLOBAL_AS dvec2 *>(p + 16);
