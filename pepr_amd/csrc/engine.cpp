@@ -61,6 +61,7 @@ int Ctx::ensure_model(int pm) {
     std::memcpy(h.U, model[pm].U, sizeof h.U);
     std::memcpy(h.Uinv, model[pm].Uinv, sizeof h.Uinv);
     std::memcpy(h.pi, model[pm].pi, sizeof h.pi);
+    for (int k = 0; k < NS; ++k) for (int j = 0; j < NS; ++j) h.UinvT[j * NS + k] = model[pm].Uinv[k * NS + j];
     HIPCHK(hipMalloc(&d_model[pm], sizeof(ModelDev)));
     HIPCHK(hipMalloc(&d_eigfrags[pm], sizeof(double) * 2 * PFRAG));
     HIPCHK(hipMemcpy(d_model[pm], &h, sizeof h, hipMemcpyHostToDevice));

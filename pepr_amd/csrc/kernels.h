@@ -24,6 +24,7 @@ struct ModelDev {
     double U[NS * NS];      // row-major U[s][k]
     double Uinv[NS * NS];   // Uinv[k][j]
     double pi[NS];
+    double UinvT[NS * NS];  // UinvT[j][k] = Uinv[k][j]: a column of Uinv contiguous (k_pmat reads it with scalar loads)
 };
 
 // request for one transition-matrix fragment set: P(t * rate_c), c = 0..3

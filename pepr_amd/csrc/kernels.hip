@@ -54,39 +54,48 @@ __device__ __forceinline__ void frag_decode(int idx, int &c, int &row, int &col)
 // ------------------------------------------------------------------------------------------
 // k_pmat: P(t r_c) = U diag(exp(lambda t r_c)) U^-1, written directly in MFMA A-fragment order
 // ------------------------------------------------------------------------------------------
-// One block per request.  Thread (row = c*20+s, group g) keeps W[k] = U[s][k] exp(lambda_k r_c t) in
-// registers and produces P_c[s][j] for j = g, g+3, g+6, ...: one LDS read per FMA instead of three.
+// One block per request.  Lane = matrix row (c, s) with W[k] = U[s][k] exp(lambda_k r_c t) in registers; each wave
+// produces five columns j, whose U^-1 column is wave-uniform and arrives by scalar loads (no LDS read per FMA).
 // PM_FRAGS / PM_FRAGS_PI write MFMA A-fragment order; PM_TIPTABLE writes T[c][code][s] =
 // sum_{j in states(code)} P_c[s][j] (the contraction of a tip's indicator vector, by lookup).
 __global__ __launch_bounds__(256) void k_pmat(const ModelDev *__restrict__ md,
                                               const PmatReq *__restrict__ reqs,
                                               double *__restrict__ frags, int n) {
     __shared__ double e[NCAT * NS];
-    __shared__ double sUi[NS * NS];
     __shared__ double sP[NCAT * NS * NS];      // staging of the result (fragment order) / P itself for tip tables
-    __shared__ double sU[NS * (NS + 1)];       // U rows, stride 21: read per lane row-wise without 20 strided global loads
-    const int tid = threadIdx.x;
+    __shared__ double sU[NS * (NS + 1)];       // U rows, stride 21
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave index in an SGPR: the column loop below is wave-uniform
     const PmatReq req = reqs[blockIdx.x];
-    for (int i = tid; i < NS * NS; i += 256) { sUi[i] = md->Uinv[i]; sU[(i / NS) * (NS + 1) + i % NS] = md->U[i]; }
+    for (int i = tid; i < NS * NS; i += 256) sU[(i / NS) * (NS + 1) + i % NS] = md->U[i];
     const double tlen = req.tp ? *req.tp : req.t;
     if (tid < NCAT * NS) e[tid] = exp(md->eval[tid % NS] * (tlen * req.rates[tid / NS]));
     __syncthreads();
     double *out = frags + (size_t)blockIdx.x * FRAG_STRIDE;
-    if (tid < 3 * NCAT * NS) {
-        const int row = tid % (NCAT * NS), g = tid / (NCAT * NS);
-        const int c = row / NS, s2 = row % NS;
+    // lane = matrix row (c, s): W[k] = U[s][k] exp(lambda_k r_c t) in registers; wave wv produces columns 5 wv .. 5 wv + 4.
+    // A column of U^-1 is the same for every lane, so it comes through SCALAR loads (SGPR operand of the FMA) -- the
+    // first version read it from LDS once per FMA and the kernel was bound by LDS issue (~6400 clk of ds_read per block).
+    for (int pass = 0; pass < 2; ++pass) {
+        const int row = pass * 64 + lane;
+        const bool ok = row < NCAT * NS;
+        const int c = ok ? row / NS : 0, s2 = ok ? row % NS : 0;
         double W[NS];
 #pragma unroll
         for (int k = 0; k < NS; ++k) W[k] = sU[s2 * (NS + 1) + k] * e[c * NS + k];
         const double scale = req.kind == PM_FRAGS_PI ? md->pi[s2] : 1.0;
-        for (int j = g; j < NS; j += 3) {
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) {
+            const int j = wv * 5 + jj;
+            const double *__restrict__ col = md->UinvT + j * NS;
             double v = 0.0;
 #pragma unroll
-            for (int k = 0; k < NS; ++k) v += W[k] * sUi[k * NS + j];
+            for (int k = 0; k < NS; ++k) v += W[k] * col[k];
             if (v < 0.0) v = 0.0;
-            if (req.kind == PM_TIPTABLE) sP[row * NS + j] = v;
-            // fragment element (c, st = s/4, kk = j/4)[4*(j%4) + s%4]: staged in LDS, written out coalesced below
-            else sP[((c * 25 + (s2 >> 2) * 5 + (j >> 2)) << 4) + ((j & 3) << 2) + (s2 & 3)] = v * scale;
+            if (ok) {
+                if (req.kind == PM_TIPTABLE) sP[row * NS + j] = v;
+                // fragment element (c, st = s/4, kk = j/4)[4*(j%4) + s%4]: staged in LDS, written out coalesced below
+                else sP[((c * 25 + (s2 >> 2) * 5 + (j >> 2)) << 4) + ((j & 3) << 2) + (s2 & 3)] = v * scale;
+            }
         }
     }
     __syncthreads();
