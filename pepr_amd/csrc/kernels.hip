@@ -58,56 +58,61 @@ __device__ __forceinline__ void frag_decode(int idx, int &c, int &row, int &col)
 // produces five columns j, whose U^-1 column is wave-uniform and arrives by scalar loads (no LDS read per FMA).
 // PM_FRAGS / PM_FRAGS_PI write MFMA A-fragment order; PM_TIPTABLE writes T[c][code][s] =
 // sum_{j in states(code)} P_c[s][j] (the contraction of a tip's indicator vector, by lookup).
-__global__ __launch_bounds__(256) void k_pmat(const ModelDev *__restrict__ md,
-                                              const PmatReq *__restrict__ reqs,
-                                              double *__restrict__ frags, int n) {
+constexpr int PMAT_THREADS = 320;      // 5 waves: 4 x (rows 0..63, five columns each) + 1 x (rows 64..79, all 20 columns)
+__global__ __launch_bounds__(PMAT_THREADS) void k_pmat(const ModelDev *__restrict__ md,
+                                                       const PmatReq *__restrict__ reqs,
+                                                       double *__restrict__ frags, int n) {
     __shared__ double e[NCAT * NS];
     __shared__ double sP[NCAT * NS * NS];      // staging of the result (fragment order) / P itself for tip tables
     __shared__ double sU[NS * (NS + 1)];       // U rows, stride 21
+    __shared__ double sUiT[NS * (NS + 1)];     // U^-1 columns, stride 21 (wave 4 only: its lanes work on different columns)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave index in an SGPR: the column loop below is wave-uniform
     const PmatReq req = reqs[blockIdx.x];
-    for (int i = tid; i < NS * NS; i += 256) sU[(i / NS) * (NS + 1) + i % NS] = md->U[i];
+    for (int i = tid; i < NS * NS; i += PMAT_THREADS) { sU[(i / NS) * (NS + 1) + i % NS] = md->U[i]; sUiT[(i / NS) * (NS + 1) + i % NS] = md->UinvT[i]; }
     const double tlen = req.tp ? *req.tp : req.t;
     if (tid < NCAT * NS) e[tid] = exp(md->eval[tid % NS] * (tlen * req.rates[tid / NS]));
     __syncthreads();
     double *out = frags + (size_t)blockIdx.x * FRAG_STRIDE;
-    // lane = matrix row (c, s): W[k] = U[s][k] exp(lambda_k r_c t) in registers; wave wv produces columns 5 wv .. 5 wv + 4.
-    // A column of U^-1 is the same for every lane, so it comes through SCALAR loads (SGPR operand of the FMA) -- the
-    // first version read it from LDS once per FMA and the kernel was bound by LDS issue (~6400 clk of ds_read per block).
-    for (int pass = 0; pass < 2; ++pass) {
-        const int row = pass * 64 + lane;
-        const bool ok = row < NCAT * NS;
-        const int c = ok ? row / NS : 0, s2 = ok ? row % NS : 0;
-        double W[NS];
+    // The 80 x 20 outputs fill five waves completely (64-lane waves over 80 rows would need a second pass at 25 % lane
+    // use; PMC showed the kernel at a VALU floor of half its run time).  Waves 0-3: lane = row 0..63, columns 5 wv ..
+    // 5 wv + 4 -- the U^-1 column is wave-uniform and arrives by scalar loads (SGPR operand of the FMA).  Wave 4: lane =
+    // (row 64 + lane%16, column group lane/16), its U^-1 column comes from LDS.
+    const bool tail = wv == 4;
+    const int row = tail ? 64 + (lane & 15) : lane;
+    const int jbase = tail ? (lane >> 4) * 5 : wv * 5;
+    const int c = row / NS, s2 = row % NS;
+    double W[NS];
 #pragma unroll
-        for (int k = 0; k < NS; ++k) W[k] = sU[s2 * (NS + 1) + k] * e[c * NS + k];
-        const double scale = req.kind == PM_FRAGS_PI ? md->pi[s2] : 1.0;
+    for (int k = 0; k < NS; ++k) W[k] = sU[s2 * (NS + 1) + k] * e[c * NS + k];
+    const double scale = req.kind == PM_FRAGS_PI ? md->pi[s2] : 1.0;
 #pragma unroll
-        for (int jj = 0; jj < 5; ++jj) {
-            const int j = wv * 5 + jj;
-            const double *__restrict__ col = md->UinvT + j * NS;
-            double v = 0.0;
+    for (int jj = 0; jj < 5; ++jj) {
+        const int j = jbase + jj;
+        double v = 0.0;
+        if (tail) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) v += W[k] * sUiT[j * (NS + 1) + k];
+        } else {
+            const double *__restrict__ col = md->UinvT + (wv * 5 + jj) * NS;
 #pragma unroll
             for (int k = 0; k < NS; ++k) v += W[k] * col[k];
-            if (v < 0.0) v = 0.0;
-            if (ok) {
-                if (req.kind == PM_TIPTABLE) sP[row * NS + j] = v;
-                // fragment element (c, st = s/4, kk = j/4)[4*(j%4) + s%4]: staged in LDS, written out coalesced below
-                else sP[((c * 25 + (s2 >> 2) * 5 + (j >> 2)) << 4) + ((j & 3) << 2) + (s2 & 3)] = v * scale;
-            }
         }
+        if (v < 0.0) v = 0.0;
+        if (req.kind == PM_TIPTABLE) sP[row * NS + j] = v;
+        // fragment element (c, st = s/4, kk = j/4)[4*(j%4) + s%4]: staged in LDS, written out coalesced below
+        else sP[((c * 25 + (s2 >> 2) * 5 + (j >> 2)) << 4) + ((j & 3) << 2) + (s2 & 3)] = v * scale;
     }
     __syncthreads();
     if (req.kind != PM_TIPTABLE) {
-        for (int idx = tid; idx < PFRAG; idx += 256) out[idx] = sP[idx];
+        for (int idx = tid; idx < PFRAG; idx += PMAT_THREADS) out[idx] = sP[idx];
         return;
     }
-    for (int idx = tid; idx < TIPTAB_DOUBLES; idx += 256) {
-        const int kk = idx % TIPTAB_KK, rec = idx / TIPTAB_KK, q = rec & 3, code = (rec >> 2) % NCODES, c = (rec >> 2) / NCODES;
+    for (int idx = tid; idx < TIPTAB_DOUBLES; idx += PMAT_THREADS) {
+        const int kk = idx % TIPTAB_KK, rec = idx / TIPTAB_KK, q = rec & 3, code = (rec >> 2) % NCODES, c2 = (rec >> 2) / NCODES;
         double v = 0.0;
         if (kk < 5) {
-            const double *prow = sP + (c * NS + 4 * kk + q) * NS;
+            const double *prow = sP + (c2 * NS + 4 * kk + q) * NS;
             if (code < NS) v = prow[code];                          // a plain state: one column
             else if (code == 20) v = prow[2] + prow[3];             // B = N | D  (same order as code_mask's bit walk)
             else if (code == 21) v = prow[5] + prow[6];             // Z = Q | E
@@ -721,7 +726,7 @@ void launch_gather(const GatherSeg *segs, int nsegs, int max_npat, hipStream_t s
 }
 void launch_pmat(const ModelDev *model, const PmatReq *reqs, double *frags, int n, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_pmat, dim3(n), dim3(256), 0, s, model, reqs, frags, n);
+    hipLaunchKernelGGL(k_pmat, dim3(n), dim3(PMAT_THREADS), 0, s, model, reqs, frags, n);
 }
 void launch_eigfrags(const ModelDev *model, double *frags2, hipStream_t s) {
     hipLaunchKernelGGL(k_eigfrags, dim3(1), dim3(256), 0, s, model, frags2);
