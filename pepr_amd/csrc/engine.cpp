@@ -387,6 +387,7 @@ void Batch::set_alpha(int g, double a) {
     G.alpha = a;
     if (ncat == 1) { for (double &r : G.rates) r = 1.0; }
     else gamma_rates(a, NCAT, G.rates);
+    ++G.rates_epoch;
     invalidate_all(g);
 }
 void Batch::invalidate_all(int g) {
@@ -726,6 +727,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         HIPCHK(hipMemcpy(P.d, ds, bytes, hipMemcpyDeviceToDevice));
         P.o_req = o_req; P.o_ops = o_ops; P.o_runs = o_runs; P.o_red = o_red;
         P.nreq = ireq; P.nruns = nruns; P.neval = neval; P.max_mpad = max_mpad; P.algo_bytes = algo_bytes; P.any_pitch = any_pitch;
+        P.rates_seen.resize(genes.size()); for (size_t g = 0; g < genes.size(); ++g) P.rates_seen[g] = genes[g].rates_epoch;
         P.src = last_src; P.outs.clear();
         for (auto &o : ops) if (o.out_kind == SIDE_MSG) P.outs.push_back({o.gene, o.out_id});
         P.epoch = topo_epoch; P.valid = true;
@@ -740,11 +742,13 @@ int Batch::replay_plan(double *lnl) {
     Plan &P = plan;
     HIPCHK(hipSetDevice(ctx->device));
     PmatReq *hreq = (PmatReq *)((char *)P.h + P.o_req);
+    std::vector<char> moved(genes.size(), 0);            // rates are rewritten only for genes whose alpha changed
+    for (size_t g = 0; g < genes.size(); ++g) if (P.rates_seen[g] != genes[g].rates_epoch) { moved[g] = 1; P.rates_seen[g] = genes[g].rates_epoch; }
     for (size_t i = 0; i < P.nreq; ++i) {
         const ReqSrc &s = P.src[i];
         const Gene &G = genes[s.gene];
         hreq[i].t = G.tree.len[s.v][s.q];
-        std::memcpy(hreq[i].rates, G.rates, sizeof hreq[i].rates);
+        if (moved[s.gene]) std::memcpy(hreq[i].rates, G.rates, sizeof hreq[i].rates);
     }
     char *ds = (char *)P.d;
     HIPCHK(hipMemcpyAsync(ds + P.o_req, hreq, P.nreq * sizeof(PmatReq), hipMemcpyHostToDevice, ctx->stream));

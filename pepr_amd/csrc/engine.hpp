@@ -51,6 +51,7 @@ struct Gene {
     Tree tree;
     double alpha = 1.0;
     double rates[NCAT] = {1, 1, 1, 1};
+    unsigned rates_epoch = 0;      // bumped by set_alpha (cached score plans refresh a gene's rates only when it moved)
     // device pointers (inside the batch arena)
     uint8_t *d_codes = nullptr;
     double *d_weight = nullptr;
@@ -114,6 +115,7 @@ struct Batch {
         size_t o_req = 0, o_ops = 0, o_runs = 0, o_red = 0, nreq = 0, nruns = 0, neval = 0;
         int max_mpad = 0; double algo_bytes = 0; bool any_pitch = false;
         std::vector<ReqSrc> src; std::vector<std::pair<int, int>> outs;
+        std::vector<unsigned> rates_seen;          // per gene: rates_epoch the descriptors carry
     } plan;
     long cnt_smooth = 0, cnt_nni = 0, cnt_spr = 0, cnt_eval = 0, cnt_passes = 0;   // run() calls by purpose (PML_TRACE)
     unsigned topo_epoch = 0;       // bumped whenever a search may change a topology
