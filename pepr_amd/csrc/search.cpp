@@ -466,6 +466,7 @@ int Batch::spr_round(const std::vector<char> &active, int radius, std::vector<do
 
 int Batch::search(bool nni, int spr_radius, bool opt_alpha_flag, double eps, double *lnl_out) {
     const int n = (int)genes.size();
+    static const bool trace = std::getenv("PML_TRACE") != nullptr;
     std::vector<double> lnl(n, 0.0);
     for (int g = 0; g < n; ++g) {         // a start tree that violates the constraints is replaced by a constrained NJ tree
         Gene &G = genes[g];
@@ -484,7 +485,7 @@ int Batch::search(bool nni, int spr_radius, bool opt_alpha_flag, double eps, dou
             bool anyr = false; for (char a : ract) anyr |= a;
             if (!anyr) break;
             if (int rc = nni_round(ract, lnl, applied)) return rc;
-            if (getenv("PML_TRACE")) { int na = 0, mv = 0; for (int g = 0; g < n; ++g) { na += ract[g]; mv += applied[g]; } fprintf(stderr, "[pml] nni round %d (outer %d): %d genes active, %d moves; cumulative smooth-steps %ld nni-steps %ld\n", round, outer, na, mv, cnt_smooth, cnt_nni); }
+            if (trace) { int na = 0, mv = 0; for (int g = 0; g < n; ++g) { na += ract[g]; mv += applied[g]; } fprintf(stderr, "[pml] nni round %d (outer %d): %d genes active, %d moves; cumulative smooth-steps %ld nni-steps %ld\n", round, outer, na, mv, cnt_smooth, cnt_nni); }
             for (int g = 0; g < n; ++g) if (ract[g]) { if (applied[g] == 0) ract[g] = 0; else moves[g] += applied[g]; }
         }
         if (spr_radius > 0) {
@@ -500,10 +501,10 @@ int Batch::search(bool nni, int spr_radius, bool opt_alpha_flag, double eps, dou
         if (int rc = optimize(opt_alpha_flag, 0.1, lnl.data(), &active)) return rc;
         for (int g = 0; g < n; ++g) if (active[g] && moves[g] == 0) active[g] = 0;
     }
-    if (getenv("PML_TRACE")) fprintf(stderr, "[pml] before final optimize: passes %ld smooth-steps %ld nni-steps %ld spr-steps %ld evals %ld\n", cnt_passes, cnt_smooth, cnt_nni, cnt_spr, cnt_eval);
+    if (trace) fprintf(stderr, "[pml] before final optimize: passes %ld smooth-steps %ld nni-steps %ld spr-steps %ld evals %ld\n", cnt_passes, cnt_smooth, cnt_nni, cnt_spr, cnt_eval);
     newton_tol = 1e-8;
     if (int rc = optimize(opt_alpha_flag, eps, lnl.data())) return rc;
-    if (getenv("PML_TRACE")) fprintf(stderr, "[pml] search done: passes %ld smooth-steps %ld nni-steps %ld spr-steps %ld evals %ld\n", cnt_passes, cnt_smooth, cnt_nni, cnt_spr, cnt_eval);
+    if (trace) fprintf(stderr, "[pml] search done: passes %ld smooth-steps %ld nni-steps %ld spr-steps %ld evals %ld\n", cnt_passes, cnt_smooth, cnt_nni, cnt_spr, cnt_eval);
     for (int g = 0; g < n; ++g) lnl_out[g] = lnl[g];
     for (int g = 0; g < n; ++g) if (!tree_displays(genes[g].tree, genes[g].cons)) return ctx->fail(-5, "internal: result violates the topological constraints");
     return 0;
