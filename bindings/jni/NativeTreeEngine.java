@@ -29,4 +29,13 @@ public final class NativeTreeEngine {
      * result[0] = full tree with integer support labels, result[1..reps] = support trees.
      */
     public static native String[] jackknife(String[][] geneTaxa, char[][][] geneRows, int reps, long seed);
+
+    /** raxmlHPC -f d -y: randomised stepwise-addition parsimony tree (topology only); seed 0 = input order. */
+    public static native String parsimony(String[] taxa, char[][] rows, int seed);
+
+    /** raxmlHPC -f a -x seed -N reps: best ML tree with percent bootstrap supports as inner labels. */
+    public static native String bootstrap(String[] taxa, char[][] rows, int reps, long seed);
+
+    /** FastTree_WAG -gamma without -nosupport: SH-like local supports (0-1 labels) on the given tree. */
+    public static native String shSupport(String[] taxa, char[][] rows, String newick, double alpha);
 }

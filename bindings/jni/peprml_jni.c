@@ -10,7 +10,7 @@
 
 #include "../../include/peprml.h"
 
-static pml_ctx *g_ctx;     /* one engine context per JVM; the library serialises concurrent calls */
+static pml_ctx *g_ctx;     /* one engine context per JVM; concurrent single-gene calls are coalesced into device batches by the library */
 
 static int ensure_ctx(void) {
     if (g_ctx) return 0;
@@ -152,5 +152,62 @@ JNIEXPORT jobjectArray JNICALL Java_edu_vt_vbi_ci_pepr_tree_NativeTreeEngine_jac
     }
     for (int g = 0; g < ng && bufs; ++g) aln_release(env, &bufs[g]);
     free(bufs); free(alns);
+    return out;
+}
+
+
+/* raxmlHPC -f d -y : parsimony start tree (topology only), RAxMLRunner.java:241-251 */
+JNIEXPORT jstring JNICALL Java_edu_vt_vbi_ci_pepr_tree_NativeTreeEngine_parsimony(
+        JNIEnv *env, jclass cls, jobjectArray taxa, jobjectArray rows, jint seed) {
+    (void)cls;
+    if (ensure_ctx()) return NULL;
+    aln_buf a; memset(&a, 0, sizeof a);
+    jstring out = NULL;
+    if (aln_from_java(env, taxa, rows, &a) == 0) {
+        pml_alignment aln = {a.n, a.len, a.names, (const char *const *)a.rows};
+        pml_parsimony_opts po = {(unsigned)seed, 20};
+        pml_result res;
+        if (pml_parsimony(g_ctx, &aln, &po, &res, NULL) == PML_OK) out = (*env)->NewStringUTF(env, res.newick);
+        pml_result_free(&res);
+    }
+    aln_release(env, &a);
+    return out;
+}
+
+/* raxmlHPC -f a -x seed -N reps : best tree with percent supports (RAxML_bipartitions.<run>), RAxMLRunner.java:115-132,302-318 */
+JNIEXPORT jstring JNICALL Java_edu_vt_vbi_ci_pepr_tree_NativeTreeEngine_bootstrap(
+        JNIEnv *env, jclass cls, jobjectArray taxa, jobjectArray rows, jint reps, jlong seed) {
+    (void)cls;
+    if (ensure_ctx()) return NULL;
+    aln_buf a; memset(&a, 0, sizeof a);
+    jstring out = NULL;
+    if (aln_from_java(env, taxa, rows, &a) == 0) {
+        pml_alignment aln = {a.n, a.len, a.names, (const char *const *)a.rows};
+        pml_model model = {4, 1.0, PML_PI_RAXML_3DP};
+        pml_result res;
+        if (pml_bootstrap(g_ctx, &aln, &model, reps, (unsigned long long)seed, 5, 1e-3, &res, NULL) == PML_OK) out = (*env)->NewStringUTF(env, res.newick);
+        pml_result_free(&res);
+    }
+    aln_release(env, &a);
+    return out;
+}
+
+/* FastTree_WAG -gamma without -nosupport : SH-like local supports (0-1) on a given tree, FastTreeRunner.java:67-70 */
+JNIEXPORT jstring JNICALL Java_edu_vt_vbi_ci_pepr_tree_NativeTreeEngine_shSupport(
+        JNIEnv *env, jclass cls, jobjectArray taxa, jobjectArray rows, jstring newick, jdouble alpha) {
+    (void)cls;
+    if (ensure_ctx() || !newick) return NULL;
+    aln_buf a; memset(&a, 0, sizeof a);
+    jstring out = NULL;
+    if (aln_from_java(env, taxa, rows, &a) == 0) {
+        pml_alignment aln = {a.n, a.len, a.names, (const char *const *)a.rows};
+        pml_model model = {4, alpha, PML_PI_WAG_FULL};
+        const char *nw = (*env)->GetStringUTFChars(env, newick, NULL);
+        pml_result res;
+        if (pml_sh_support(g_ctx, &aln, nw, &model, 1000, 314159ULL, &res) == PML_OK) out = (*env)->NewStringUTF(env, res.newick);
+        pml_result_free(&res);
+        (*env)->ReleaseStringUTFChars(env, newick, nw);
+    }
+    aln_release(env, &a);
     return out;
 }
