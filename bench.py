@@ -169,7 +169,9 @@ def main():
         # of a long-lived context, which keeps the arena; both are whole inferences and both are reported
         cold, _, _, sb = infer()
         sb.close()
+        sctx.kernel_stats(reset=True)
         sdt, tc, slnl, sb = infer()
+        sst = sctx.kernel_stats()
         rf = [engine.rf_distance(genes[i][2], sb.newick(i)) for i in range(len(genes))]
         sb.close(); sctx.close()
         if world > 1:
@@ -178,7 +180,11 @@ def main():
         search = {"gene_trees_per_sec": per_gpu * world / sdt, "seconds": sdt, "setup_seconds_rank0": tc,
                   "cold_first_call_seconds": cold, "cold_gene_trees_per_sec": per_gpu * world / cold, "genes": per_gpu * world,
                   "algorithm": "NJ start + WAG+G4 model optimisation + NNI hill climbing (eps 1e-3); timed from host char rows to Newick",
-                  "rf_to_generating_tree_mean_rank0": float(np.mean(rf)), "finite": bool(np.all(np.isfinite(slnl)))}
+                  "rf_to_generating_tree_mean_rank0": float(np.mean(rf)), "finite": bool(np.all(np.isfinite(slnl))),
+                  # no closed form for a search -> measured call counts x the per-pattern byte figures / time
+                  "work_rank0": {"launches": {k: v["launches"] for k, v in sst.items() if v["launches"] and not k.startswith("host")},
+                                 "algorithmic_GB": {k: v["algo_bytes"] / 1e9 for k, v in sst.items() if v["algo_bytes"]},
+                                 "algorithmic_TB_per_s": sum(v["algo_bytes"] for k, v in sst.items() if k in ("newview", "newton")) / sdt / 1e12}}
 
     if rank == 0:
         nv = stats["newview"]
