@@ -195,7 +195,7 @@ def main():
         if os.path.exists(pmc):       # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
             traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
         out = {
-            "metric": "M site-lnL/sec (WAG+G4 full-tree likelihood evaluations x alignment patterns)",
+            "metric": "M site-lnL/sec (WAG+G4 full-tree likelihood evaluations x alignment patterns); the gene-trees/sec half of BASELINE.json's metric is search.gene_trees_per_sec",
             "value": tot_pat * args.steps / dt / 1e6, "unit": "M site-lnL/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
