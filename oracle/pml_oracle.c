@@ -1187,7 +1187,6 @@ double po_engine_search(po_engine *e, po_tree **t_inout, int spr_radius, double 
         if (!moves) break;
     }
     e->ntol = 1e-8;
-    e->dirty = (unsigned char *)calloc((size_t)e->nnodes * 3, 1); e->dirty_next = (unsigned char *)calloc((size_t)e->nnodes * 3, 1);
     return po_engine_optimize(e, t, 1, eps);
 }
 

@@ -23,3 +23,18 @@ def test_host_code_under_asan(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1"))
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     assert "checks ok" in r.stdout
+
+
+def test_oracle_under_asan(tmp_path):
+    """the CPU oracle (plain C) with the same sanitizers: every public entry point once on small random data"""
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "oracle_driver")
+    cmd = ["gcc", "-std=gnu11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+           os.path.join(ROOT, "tests", "host_asan", "oracle_driver.c"), os.path.join(ROOT, "oracle", "pml_oracle.c"), "-lm", "-o", exe]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in b.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1"))
+    assert r.returncode == 0 and "oracle asan driver ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
