@@ -101,7 +101,7 @@ struct NewtonReq {          // Newton-Raphson on one branch from its sumtable
     int max_iter;           // 0: derivatives at t0 only
 };
 constexpr int NEWTON_MAX_SPLIT = 64;    // 128-pattern slices up to 8192 patterns stay register-resident (k_newton)
-constexpr int NEWTON_SYNC_DOUBLES = 2 + 2 * NEWTON_MAX_SPLIT * 3 + 14;   // 400 doubles = 3.2 KB
+constexpr int NEWTON_SYNC_DOUBLES = 2 + 2 * NEWTON_MAX_SPLIT * 3 + NEWTON_MAX_SPLIT + 6;   // header, two parities of partial sums, one arrival tag per slice: 456 doubles
 
 enum { MODE_NEWVIEW = 0, MODE_SUMTABLE = 1, MODE_EVALUATE = 2 };
 

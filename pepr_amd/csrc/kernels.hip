@@ -522,8 +522,8 @@ __global__ __launch_bounds__(256, 3) void k_newton(const ModelDev *__restrict__ 
     const int slice = ((mpad / 32 + S - 1) / S) * 32;
     const bool REG = slice <= 128;
     const int p_begin = wg * slice, p_end = min(mpad, p_begin + slice);
-    unsigned *cnt = reinterpret_cast<unsigned *>(r.sync);
     double *part = r.sync + 2;
+    unsigned long long *tags = reinterpret_cast<unsigned long long *>(r.sync + 2 + 2 * NEWTON_MAX_SPLIT * 3);
     int nevals = 0;
     bool failed = false;
     double xr[CLV_ROWS / 2]; double rw = 0.0, rscl = 0.0; const int rhalf = tid & 1;
@@ -574,16 +574,23 @@ __global__ __launch_bounds__(256, 3) void k_newton(const ModelDev *__restrict__ 
         }
         block_sum<3, 4>(acc, red);
         if (S > 1) {
+            // exchange: every slice posts its three partial sums, then an arrival TAG (= evaluation number) behind them;
+            // the first wave polls all S tags at once, one lane per slice.  No read-modify-write on the critical path
+            // (an arrival counter cost one more fabric round trip per evaluation).
+            const unsigned long long want = (unsigned long long)(nevals + 1);
             if (tid == 0) {
                 double *mine = part + ((nevals & 1) * NEWTON_MAX_SPLIT + wg) * 3;
                 st_agent(mine, acc[0]); st_agent(mine + 1, acc[1]); st_agent(mine + 2, acc[2]);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned target = (unsigned)S * (unsigned)(nevals + 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the sums are out before the tag
+                __hip_atomic_store(tags + wg, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid < 64) {
                 long spins = 0;
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > 20000000L) { bc[3] = 1.0; break; }      // bounded: never hang the GPU
+                for (;;) {
+                    const unsigned long long tg = (tid < S) ? __hip_atomic_load(tags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+                    if (__all(tg >= want)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > 20000000L) { if (tid == 0) bc[3] = 1.0; break; }      // bounded: never hang the GPU
                 }
             }
             __syncthreads();
