@@ -152,6 +152,25 @@ int main(int argc, char **argv) {
     if (aln_f.empty() || run.empty()) return fail(tool, "usage: raxmlHPC -f d|e|g -m PROTGAMMAWAG -s aln.phy -n run [-t tree] [-z trees]");
     if (model_s.find("WAG") == std::string::npos || model_s.compare(0, 4, "PROT") != 0) return fail(tool, "only PROT*WAG* models are built, got " + model_s);
     if (std::ifstream("RAxML_info." + run)) return fail(tool, "RAxML output files with the run ID <" + run + "> already exist");
+    if (f == "b") {                                       // RAxMLRunner.java:453-516: draw the bipartition frequencies of -z trees on -t tree (host only)
+        if (tree_f.empty() || trees_f.empty()) return fail(tool, "-f b needs -t tree -z trees");
+        const std::string main_tree = read_file(tree_f.c_str());
+        std::ifstream tf(trees_f); std::string line; std::vector<std::string> trees;
+        while (std::getline(tf, line)) { bool blank = true; for (char c : line) if (!std::isspace((unsigned char)c)) blank = false; if (!blank) trees.push_back(line); }
+        std::vector<const char *> tp; for (auto &t : trees) tp.push_back(t.c_str());
+        char *out = nullptr;
+        if (int rc = pml_support_tree(main_tree.c_str(), (int)tp.size(), tp.data(), 20, &out)) return fail(tool, std::string("-f b: ") + pml_strerror(rc) + " " + pml_last_error(nullptr));
+        // RAxML prints percentages; pml_support_tree counts trees
+        std::string res; const int nt = (int)tp.size();
+        for (const char *p = out; *p; ++p) {
+            res += *p;
+            if (*p == ')' && std::isdigit((unsigned char)p[1])) { char *e; const long c = std::strtol(p + 1, &e, 10); res += std::to_string(nt ? (int)(0.5 + 100.0 * c / nt) : 0); p = e - 1; }
+        }
+        pml_free(out);
+        std::ofstream("RAxML_bipartitions." + run) << reformat(res.c_str(), 20, true) << "\n";
+        std::ofstream("RAxML_info." + run) << "peprml raxmlHPC shim: -f b, " << nt << " trees drawn on " << tree_f << "\n";
+        return 0;
+    }
     Aln a; std::string err;
     if (!read_phylip(aln_f.c_str(), a, err)) return fail(tool, err);
     pml_ctx *ctx = nullptr; pml_config cfg = {0, 0, 0};
@@ -228,7 +247,7 @@ int main(int argc, char **argv) {
             }
             pml_result_free(&o);
         }
-    } else { pml_destroy(ctx); return fail(tool, "-f " + f + " is not built (a, d, e, g are)"); }
+    } else { pml_destroy(ctx); return fail(tool, "-f " + f + " is not built (a, b, d, e, g are)"); }
     if (rc) { std::string m = pml_last_error(ctx); pml_destroy(ctx); return fail(tool, m); }
     pml_destroy(ctx);
     return 0;

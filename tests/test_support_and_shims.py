@@ -95,3 +95,17 @@ def test_refine_next_follows_refiner_rules():
     assert engine.refine_next(nw3, 100)[0] is None
     with pytest.raises(engine.PmlError):
         engine.refine_next("((a,b)x9,c);", 100)
+
+
+def test_raxml_shim_f_b_draws_bipartitions(tmp_path):
+    """`raxmlHPC -f b -z trees -t tree` (RAxMLRunner.getSupportDecoratedTree :453-516): host-only, percent labels"""
+    import re
+    (tmp_path / "main.nwk").write_text("((a:0.1,b:0.1):0.1,(c:0.1,d:0.1):0.1,e:0.1);\n")
+    (tmp_path / "sup.nwk").write_text("((a,b),(c,d),e);\n((a,b),(c,e),d);\n((a,c),(b,d),e);\n((a,b),c,(d,e));\n")
+    (tmp_path / "x.phy").write_text("5 2\na AR\nb AR\nc AR\nd AR\ne AR\n")
+    r = subprocess.run([RX, "-f", "b", "-z", "sup.nwk", "-t", "main.nwk", "-T", "2", "-m", "PROTGAMMAWAG", "-n", "b1", "-s", "x.phy"],
+                       cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = (tmp_path / "RAxML_bipartitions.b1").read_text().strip()
+    assert sorted(int(x) for x in re.findall(r"\)(\d+):", out)) == [25, 75]        # (c,d) in 1 of 4, (a,b) in 3 of 4
+    assert out.endswith(":0.0;")
