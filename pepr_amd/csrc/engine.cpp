@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cmath>
 #include <thread>
+#include <unordered_map>
 #include <cstring>
 
 namespace pml {
@@ -220,6 +221,7 @@ void Batch::destroy() {
     if (h_scalars) hipHostFree(h_scalars);
     if (h_chain) hipHostFree(h_chain);
     if (d_lenpool) hipFree(d_lenpool);
+    if (d_tailpool) { hipFree(d_tailpool); d_tailpool = nullptr; tailpool_cap = 0; }
     if (d_site2pat) { hipFree(d_site2pat); d_site2pat = nullptr; }
     h_chain = d_chain = nullptr; d_lenpool = nullptr; chain_cap = 0;
     arena = nullptr; h_stage = d_stage = nullptr; d_frags = nullptr; d_scalars = h_scalars = nullptr;
@@ -335,7 +337,7 @@ int Batch::chain_sync() {
     chain_off = 0;
     return 0;
 }
-int Batch::chain_begin(size_t nresults) {
+int Batch::ensure_results(size_t nresults) {
     if (nresults > chain_cap) {
         if (h_chain) hipHostFree(h_chain);
         h_chain = d_chain = nullptr; chain_cap = 0;
@@ -344,6 +346,18 @@ int Batch::chain_begin(size_t nresults) {
         HIPCHK(hipHostGetDevicePointer((void **)&d_chain, h_chain, 0));
         chain_cap = cap;
     }
+    return 0;
+}
+int Batch::ensure_tailpool(size_t bytes) {
+    if (bytes <= tailpool_cap) return 0;
+    if (d_tailpool) hipFree(d_tailpool);
+    d_tailpool = nullptr; tailpool_cap = 0;
+    if (hipMalloc((void **)&d_tailpool, bytes) != hipSuccess) { d_tailpool = nullptr; return ctx->fail(-4, "sumtable pool of " + std::to_string(bytes >> 20) + " MiB does not fit"); }
+    tailpool_cap = bytes;
+    return 0;
+}
+int Batch::chain_begin(size_t nresults) {
+    if (int rc = ensure_results(nresults)) return rc;
     if (!d_lenpool) {
         size_t tot = 0; for (auto &G : genes) tot += (size_t)G.tree.nnodes() * 3;
         HIPCHK(hipMalloc((void **)&d_lenpool, tot * sizeof(double)));
@@ -500,7 +514,19 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     const size_t nops = ops.size(), ntail = tails.size();
     size_t neval = 0, nnewton = 0;
     for (auto &t : tails) { if (t.mode == MODE_EVALUATE) neval++; else nnewton++; }
-    const size_t nreq_max = 10 * nops + 9 * ntail;         // <= 5 requests per side (pitchfork: 3 tables + 2 fragment sets)
+    // <= 5 requests per side (pitchfork: 3 tables + 2 fragment sets) -- but requests across the same tree branch are
+    // shared within the launch (add_req), so a gene never needs more than 5 per taxon plus those of lengths that
+    // belong to no branch of the tree (SPR path / insertion operations)
+    size_t nreq_max = 10 * nops + 9 * ntail;
+    {
+        std::vector<char> seen(genes.size(), 0);
+        size_t keyed = 0, loose = 0;
+        for (auto &o : ops) { if (!seen[o.gene]) { seen[o.gene] = 1; keyed += 5 * (size_t)genes[o.gene].aln.ntax; }
+                              if (o.out_kind != SIDE_MSG && (o.bv[0] < 0 || o.bv[1] < 0)) loose += 10; }
+        for (auto &t : tails) { if (!seen[t.gene]) { seen[t.gene] = 1; keyed += 5 * (size_t)genes[t.gene].aln.ntax; }
+                                if (t.mode == MODE_EVALUATE && t.bv < 0) loose += 9; }
+        nreq_max = std::min(nreq_max, keyed + loose);
+    }
     bool any_pitch = false;
     if (int rc = ensure_frags(std::max(nreq_max, (size_t)1))) return rc;
     double *&nsync_buf = lane ? d_nsync2 : d_nsync; size_t &nsync_c = lane ? nsync_cap2 : nsync_cap;
@@ -539,12 +565,26 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     int max_mpad = 0, newton_maxm = 0;
     double algo_bytes = 0;
     // one transition-matrix request (fragment set or tip table) for branch (v, slot q) of gene g
+    // one request per (gene, kind, tree branch) and launch; never while a plan is being recorded (a replay refreshes
+    // each request from ITS branch)
+    std::unordered_map<uint64_t, const double *> shared;
+    bool req_overflow = false;
     auto add_req = [&](size_t g, double t, int kind, int v, int q) -> const double * {
+        uint64_t key = 0;
+        if (v >= 0 && !record_plan) {
+            const int w = genes[g].tree.nbr[v][q], a = v * 3 + q, b = w * 3 + genes[g].tree.slot(w, v);
+            key = ((uint64_t)g << 34) | ((uint64_t)kind << 32) | (uint64_t)(uint32_t)std::min(a, b);
+            auto it = shared.find(key);
+            if (it != shared.end()) return it->second;
+        }
+        if (ireq >= nreq_max) { req_overflow = true; return frags_buf; }
         PmatReq &r = hreq[ireq];
         r.t = t; std::memcpy(r.rates, genes[g].rates, sizeof r.rates); r.kind = kind; r.pad = 0;
         r.tp = (chain && v >= 0 && genes[g].len_pending[(size_t)v * 3 + q]) ? genes[g].d_len + (size_t)v * 3 + q : nullptr;
         last_src.push_back({(int)g, v, q, kind});
-        return frags_buf + (ireq++) * FRAG_STRIDE;
+        const double *out = frags_buf + (ireq++) * FRAG_STRIDE;
+        if (v >= 0 && !record_plan) shared.emplace(key, out);
+        return out;
     };
     // resolves one side of an op: pointers, kind, scaling counts; `want_table`: newview tip sides look
     // their contraction up in a tip table; `t_branch`/(bv,bq): the branch between this side and the op
@@ -621,10 +661,12 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
                 algo_bytes += (double)G.aln.npat * (L.bytes + R.bytes + 8);
             } else {
                 d.pl = eig; d.pr = eig + PFRAG;
-                d.out = G.d_sumtab[t.slot]; d.out_scl = G.d_sumscl[t.slot];
+                double *stab = t.sumtab_dev ? t.sumtab_dev : G.d_sumtab[t.slot];
+                int *sscl = t.sumtab_dev ? reinterpret_cast<int *>(t.sumtab_dev + (size_t)CLV_ROWS * mp) : G.d_sumscl[t.slot];
+                d.out = stab; d.out_scl = sscl;
                 d.aux = nsync_buf + (size_t)in * NEWTON_SYNC_DOUBLES;
                 NewtonReq &nr = hnewt[in];
-                nr.sumtab = G.d_sumtab[t.slot]; nr.weight = G.d_weight; nr.scl = G.d_sumscl[t.slot];
+                nr.sumtab = stab; nr.weight = G.d_weight; nr.scl = sscl;
                 std::memcpy(nr.rates, G.rates, sizeof nr.rates);
                 nr.t0 = t.t0; nr.tol = newton_tol; nr.out = result; nr.mpad = mp; nr.max_iter = t.max_iter;
                 nr.t_dev0 = t.t_dev0; nr.t_dev1 = t.t_dev1; nr.patlnl = t.patlnl_dev;
@@ -661,7 +703,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             const double *pm[2];
             for (int c = 0; c < 2; ++c) {
                 // where this child's branch length lives (plan replay): output message (v, k), child c
-                int bv = -1, bq = 0;
+                int bv = o.bv[c], bq = o.bq[c];
                 if (o.out_kind == SIDE_MSG) {
                     bv = G.aln.ntax + o.out_id / 3; const int k = o.out_id % 3;
                     int seen = 0;
@@ -678,6 +720,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         run.op_end = (int)nout;
     }
 
+    if (req_overflow) return ctx->fail(-5, "internal: transition-matrix request bound exceeded");
     HIPCHK(hipMemcpyAsync(ds, hs, bytes, hipMemcpyHostToDevice, st));
     const ModelDev *md = ctx->d_model[pi_mode];
     if (ireq) {
@@ -712,6 +755,13 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         const double t_done = now_ms();
         ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += t_done - t_launched;
         ctx->resolve_events();
+        // a Newton request whose cross-workgroup exchange timed out reports lnL = NaN (k_newton): that is a device
+        // failure, never a result
+        for (auto &t : tails) {
+            const double *h = t.result_host ? t.result_host : (t.result_dev ? nullptr : res(t.gene, t.slot));
+            if (h && !std::isfinite(t.mode == MODE_EVALUATE ? h[0] : h[1]))
+                return ctx->fail(-5, t.mode == MODE_EVALUATE ? "device returned a non-finite likelihood" : "k_newton: cross-workgroup exchange timed out (non-finite result)");
+        }
     }
     for (auto &o : ops) if (o.out_kind == SIDE_MSG) { Gene &G = genes[o.gene]; G.valid[o.out_id] = 1; G.pend_level[o.out_id] = -1; }
     if (record_plan) {                       // keep the descriptors of this full-traversal score
@@ -932,6 +982,8 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
         if (int rc = chain_sync()) { chain = false; return rc; }
         ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += now_ms() - t0;
         chain = false;
+        for (auto &d : done) if (!std::isfinite(h_chain[4 * d.idx + 1]))
+            return ctx->fail(-5, "k_newton: cross-workgroup exchange timed out (non-finite result)");
         for (auto &d : done) {
             Gene &G = genes[d.gene];
             const double nl = h_chain[4 * d.idx], dl = std::fabs(nl - d.old);

@@ -88,7 +88,9 @@ enum { SIDE_TIP = 0, SIDE_MSG = 1, SIDE_SCRATCH = 2, SIDE_CHERRY = 3, SIDE_PITCH
 // tip node id | directed-edge index (v-ntax)*3+k | scratch slot | directed-edge index of a message whose
 // two children are tips ("cherry": never materialised, recomputed from two tip tables where consumed)
 struct Side { int kind, id; };
-struct PendingOp { int gene, out_kind, out_id, level; Side child[2]; double t[2]; };
+// bv/bq (optional, scratch outputs): the tree branch (node, slot) child c's length belongs to -- lets run() share ONE
+// transition-matrix request among all operations of a launch that cross the same branch
+struct PendingOp { int gene, out_kind, out_id, level; Side child[2]; double t[2]; int bv[2] = {-1, -1}, bq[2] = {0, 0}; };
 
 struct Batch {
     Ctx *ctx = nullptr;
@@ -129,6 +131,10 @@ struct Batch {
     double *d_lenpool = nullptr;
     double *d_chain = nullptr, *h_chain = nullptr; size_t chain_cap = 0;     // 4 doubles per chained Newton result
     int chain_begin(size_t nresults);
+    int ensure_results(size_t nresults);   // h_chain / d_chain: 4 mapped doubles per pooled Newton result
+    // pooled sumtables for launches that carry more Newton requests per gene than MAXTAIL (all edges of an NNI round)
+    char *d_tailpool = nullptr; size_t tailpool_cap = 0;
+    int ensure_tailpool(size_t bytes);
     int chain_sync();                  // wait for everything enqueued; the staging buffer is free again
 
     int create(Ctx *c, int n, const pml_alignment_view *alns, const char *const *newicks,
@@ -173,7 +179,9 @@ struct Batch {
                   int bv = -1, bq = 0; /* tree branch (node, slot) t0 comes from: plan replay */
                   double *result_dev = nullptr;               /* chained pass: where k_newton writes (else res(g, slot)) */
                   double *t_dev0 = nullptr, *t_dev1 = nullptr; /* chained pass: d_len entries of the branch */
-                  double *patlnl_dev = nullptr;               /* Newton tails: per-pattern lnL at the optimised length */ };
+                  double *patlnl_dev = nullptr;               /* Newton tails: per-pattern lnL at the optimised length */
+                  double *sumtab_dev = nullptr;               /* Newton tails: pooled sumtable (80*mpad doubles + mpad ints) instead of the gene's slot buffer */
+                  const double *result_host = nullptr;        /* host view of result_dev when it is mapped memory (checked after the sync) */ };
     double *res(int g, int slot = 0) const { return h_scalars + 8 * ((size_t)g * MAXTAIL + slot); }
     Side msg(int g, int node, int toward) const;
     bool is_cherry(int g, int node, int toward) const;

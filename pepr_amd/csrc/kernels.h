@@ -94,14 +94,14 @@ struct NewtonReq {          // Newton-Raphson on one branch from its sumtable
     double t0;
     double tol;             // stop when |dt| < tol
     double *out;            // out[0]=t, out[1]=lnL, out[2]=d1, out[3]=d2 (at returned t)
-    double *sync;           // NEWTON_SYNC_DOUBLES zeroed doubles: arrival counter + per-workgroup partial sums
+    double *sync;           // NEWTON_SYNC_DOUBLES zeroed 8-byte words: the slices' {tag, value} exchange granules (k_newton)
     double *t_dev0, *t_dev1; // optional: device-resident copies of the branch length (both directions) for chaining
     double *patlnl;         // optional: per-pattern lnL (scaling applied) at the returned length, [mpad] (SH-like supports)
     int mpad;
     int max_iter;           // 0: derivatives at t0 only
 };
 constexpr int NEWTON_MAX_SPLIT = 64;    // 128-pattern slices up to 8192 patterns stay register-resident (k_newton)
-constexpr int NEWTON_SYNC_DOUBLES = 2 + 2 * NEWTON_MAX_SPLIT * 3 + NEWTON_MAX_SPLIT + 6;   // header, two parities of partial sums, one arrival tag per slice: 456 doubles
+constexpr int NEWTON_SYNC_DOUBLES = 2 * NEWTON_MAX_SPLIT * 6;   // two parities x slices x six 8-byte {tag, half a double} granules (three partial sums)
 
 enum { MODE_NEWVIEW = 0, MODE_SUMTABLE = 1, MODE_EVALUATE = 2 };
 

@@ -474,149 +474,204 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceReq *__restrict__ re
 // k_newton: Newton-Raphson on one branch length from its eigen-basis sumtable (RAxML "makenewz",
 // SURVEY 8a-11 v).  The whole iteration runs on the device.  A single CU streams the 640 B/pattern
 // sumtable at only ~70 GB/s (one CU's L2 rate), so a request is SPLIT over S workgroups (pattern
-// slices) that exchange three partial sums per evaluation through global memory:
-//   producer: sc1 (agent-scope relaxed atomic) stores of the partials -> s_waitcnt vmcnt(0) ->
-//             agent-scope atomic add on the arrival counter;
-//   consumer: sc1 poll of the counter -> sc1 loads of all S partials, summed in slice order
-//             (bit-reproducible) -> LDS broadcast + workgroup barrier.
-// (cdna_hip_programming.md Guideline 16, "every load sc1" form.)  All S x n workgroups of a launch
-// are co-resident (launch_newton caps the grid), every workgroup of a request executes the same
-// evaluations because they all see identical sums, and the spin is bounded.
+// slices of <= 128 patterns whose sumtable rows stay in registers for the whole iteration) that
+// exchange three partial sums per evaluation through global memory.
+//
+// Exchange = data-tagged granules (cdna_hip_programming.md Guideline 16, form R2): every partial sum
+// travels as two naturally aligned 8-byte words {tag = evaluation number, 32 bits of the double},
+// each written by ONE relaxed agent-scope atomic store and read by relaxed agent-scope atomic loads.
+// A granule is indivisible, so a consumer can never pair a tag with bytes of another evaluation;
+// no ordering between different words is needed (no flag, no fence, no s_waitcnt).  A slot is only
+// overwritten two evaluations later (parity double buffer), which its producer can reach only after
+// every consumer has finished the evaluation in between.  (Round 1 posted the sums and a separate
+// arrival tag ordered by s_waitcnt: a form measured only at one workgroup per CU; a consumer that saw
+// the tag before a sum is the likely cause of the last-bit difference once seen between a lone and
+// a coalesced call.)  The sums of all slices are combined in a fixed tree order that depends on S
+// alone, S depends on the request alone: bit-reproducible whatever else is in the launch.
+// Every workgroup of a request executes the same evaluations because all see identical sums.
+// Forward progress: workgroups are dispatched in grid order (x fastest), so the lowest unfinished
+// request always has its <= 64 slices resident or next in line; the spin is bounded anyway and a
+// timeout is REPORTED: lnL = NaN, which the host turns into PML_EDEVICE (engine.cpp check_newton).
 // Control flow is the oracle's eng_newton_branch().
 // ------------------------------------------------------------------------------------------
 #define PML_TMIN 1.0e-6
 #define PML_TMAX 34.5
 
-__device__ __forceinline__ void st_agent(double *p, double v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+__device__ __forceinline__ void st_granule(u64 *p, u64 v) {
+    __hip_atomic_store((gu64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ double ld_agent(const double *p) {
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
-                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+__device__ __forceinline__ u64 ld_granule(const u64 *p) {
+    return __hip_atomic_load((const gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ double lane_swap1(double v) {      // value of the neighbouring lane (lane ^ 1), DPP quad_perm [1,0,3,2]
+template <int CTRL>           // DPP quad_perm: 0xB1 = [1,0,3,2] (lane ^ 1), 0x4E = [2,3,0,1] (lane ^ 2)
+__device__ __forceinline__ double quad_swap(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double quad_sum(double v) { v += quad_swap<0xB1>(v); v += quad_swap<0x4E>(v); return v; }
 
-// REG: the workgroup's slice is <= 128 patterns and stays in registers for the whole iteration: lane pair
-// (2j, 2j+1) owns pattern j, each lane 40 of its 80 sumtable rows (read once from HBM/L2 instead of once
-// per evaluation); the halves are combined with one DPP swap.
-__global__ __launch_bounds__(256, 3) void k_newton(const ModelDev *__restrict__ md,
-                                                   const NewtonReq *__restrict__ reqs) {
-    __shared__ double exl[NCAT * NS][2];          // (exp(lambda_i r_k t), lambda_i r_k)
-    __shared__ double red[3][4];
-    __shared__ double bc[4];
-    __shared__ double gp[3][NEWTON_MAX_SPLIT];
-    const NewtonReq r = reqs[blockIdx.y];
-    const int tid = threadIdx.x, mpad = r.mpad, wg = blockIdx.x;
+// wave-uniform double kept in an SGPR pair (the Newton state is identical in every lane; as VGPRs it would cost 16 of 64)
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+constexpr int NEWTON_THREADS = 512;           // 8 waves: 7 compute waves (four lanes per pattern -> 112 patterns) + 1 service wave
+constexpr int NEWTON_CWAVES = NEWTON_THREADS / 64 - 1;
+constexpr int NEWTON_SLICE = NEWTON_CWAVES * 16;          // patterns per register-resident slice
+constexpr int NEWTON_ROWS = CLV_ROWS / 4;     // sumtable rows per lane (20 doubles = 40 VGPRs)
+constexpr long NEWTON_SPIN_LIMIT = 4000000L;  // polls (~1 us each) before a slice gives up
+
+struct NewtonShared {
+    double exl[NCAT * NS][2];                 // (exp(lambda_i r_k t), lambda_i r_k)
+    double red[3][NEWTON_CWAVES];             // streaming form: the compute waves' sums
+    double fb[3][NEWTON_SLICE];               // register form: per pattern f, f', f'' (the service wave finishes them)
+    double bc[4];
+};
+
+// Wave specialisation.  The SERVICE wave (SP) computes the 80 exponentials of every evaluation, combines the compute
+// waves' sums and runs the exchange; the COMPUTE waves hold the slice in registers (REG: lanes 4j..4j+3 own pattern j,
+// each 20 of its 80 sumtable rows, read once from HBM/L2 instead of once per evaluation; quarters combined with two DPP
+// quad swaps) or stream it (slices > 112 patterns: genes of more than 7168 patterns).  The two roles are two
+// instantiations of one body, so the register-hungry f64 exp never meets the 40 live sumtable registers: 8 waves per
+// SIMD = 4 workgroups per CU.  All waves execute the same Newton control flow on the same broadcast sums, so they meet at
+// the same three barriers per evaluation.
+template <bool REG, bool SP>
+__device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, const NewtonReq &r, NewtonShared &sh,
+                                            int S, int wg, int p_begin, int p_end) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mpad = r.mpad;
     const size_t M = (size_t)mpad;
-    // the split depends on the request alone (not on what else is in the launch): results are reproducible
-    // whatever the batch composition
-    const int S = min(NEWTON_MAX_SPLIT, (mpad + 127) / 128);
-    if (wg >= S) return;
-    const int slice = ((mpad / 32 + S - 1) / S) * 32;
-    const bool REG = slice <= 128;
-    const int p_begin = wg * slice, p_end = min(mpad, p_begin + slice);
-    double *part = r.sync + 2;
-    unsigned long long *tags = reinterpret_cast<unsigned long long *>(r.sync + 2 + 2 * NEWTON_MAX_SPLIT * 3);
+    u64 *gran = reinterpret_cast<u64 *>(r.sync);       // [parity 2][slice NEWTON_MAX_SPLIT][6] granules, zeroed by the sumtable op
     int nevals = 0;
     bool failed = false;
-    double xr[CLV_ROWS / 2]; double rw = 0.0, rscl = 0.0; const int rhalf = tid & 1;
-    if (REG) {
-        const int p = p_begin + (tid >> 1);
-        if (p < p_end) { rw = r.weight[p]; rscl = (double)r.scl[p]; }
-#pragma unroll
-        for (int i = 0; i < CLV_ROWS / 2; ++i) xr[i] = (rw != 0.0) ? r.sumtab[(size_t)(rhalf * (CLV_ROWS / 2) + i) * M + p] : 0.0;
+    double xr[NEWTON_ROWS]; double rw = 0.0, rscl = 0.0; const int sub = tid & 3;
+    double sw0 = 0.0, ss0 = 0.0, sw1 = 0.0, ss1 = 0.0;   // service wave: weights and scaling counts of its two patterns
+    if (REG && SP) {
+        const int p0 = p_begin + lane, p1 = p_begin + 64 + lane;
+        if (p0 < p_end) { sw0 = r.weight[p0]; ss0 = (double)r.scl[p0]; }
+        if (lane < NEWTON_SLICE - 64 && p1 < p_end) { sw1 = r.weight[p1]; ss1 = (double)r.scl[p1]; }
     }
-
-    auto eval_at = [&](double t, double &L, double &d1, double &d2) {
-        if (tid < NCAT * NS) {
-            const double lr = md->eval[tid % NS] * r.rates[tid / NS];
-            exl[tid][0] = exp(lr * t); exl[tid][1] = lr;
-        }
-        __syncthreads();
-        double acc[3] = {0.0, 0.0, 0.0};
-        if (REG) {
-            double f = 0.0, f1 = 0.0, f2 = 0.0;
+    if (REG && !SP) {
+        // lanes beyond the slice read its last pattern (a valid address) and carry weight 0: no per-load branches
+        const int p = p_begin + (tid >> 2), pc = min(p, p_end - 1);
+        if (p < p_end) { rw = r.weight[p]; rscl = (double)r.scl[p]; }
+        const double *col = r.sumtab + (size_t)(sub * NEWTON_ROWS) * M + pc;
 #pragma unroll
-            for (int i = 0; i < CLV_ROWS / 2; ++i) {
-                const int row = rhalf * (CLV_ROWS / 2) + i;
-                const double xe = xr[i] * exl[row][0], xl = xe * exl[row][1];
-                f += xe; f1 += xl; f2 += xl * exl[row][1];
-                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);      // at most 8 LDS pairs in flight
-            }
-            f += lane_swap1(f); f1 += lane_swap1(f1); f2 += lane_swap1(f2);
-            if (rhalf == 0 && rw != 0.0) {
-                const double r1 = f1 / f;
-                acc[0] = rw * (log(f * 0.25) - rscl * LOG_2_256);
-                acc[1] = rw * r1;
-                acc[2] = rw * (f2 / f - r1 * r1);
-            }
-        } else
-        for (int p = p_begin + tid; p < p_end; p += 256) {
-            const double w = r.weight[p];
-            if (w == 0.0) continue;
-            double f = 0.0, f1 = 0.0, f2 = 0.0;
-#pragma unroll 16
-            for (int row = 0; row < CLV_ROWS; ++row) {
-                const double xe = r.sumtab[(size_t)row * M + p] * exl[row][0], xl = xe * exl[row][1];
-                f += xe; f1 += xl; f2 += xl * exl[row][1];
-            }
-            const double r1 = f1 / f;
-            acc[0] += w * (log(f * 0.25) - r.scl[p] * LOG_2_256);
-            acc[1] += w * r1;
-            acc[2] += w * (f2 / f - r1 * r1);
+        for (int i = 0; i < NEWTON_ROWS; ++i) xr[i] = col[(size_t)i * M];
+    }
+    auto fill_exl = [&](double t) {        // service wave: lane l computes rows l and (l < 16) 64 + l
+#pragma unroll 1                           // one exp chain at a time: interleaved they double the temporaries
+        for (int k = lane; k < NCAT * NS; k += 64) {
+            const double lr = md->eval[k % NS] * r.rates[k / NS];
+            sh.exl[k][0] = exp(lr * t); sh.exl[k][1] = lr;
         }
-        block_sum<3, 4>(acc, red);
-        if (S > 1) {
-            // exchange: every slice posts its three partial sums, then an arrival TAG (= evaluation number) behind them;
-            // the first wave polls all S tags at once, one lane per slice.  No read-modify-write on the critical path
-            // (an arrival counter cost one more fabric round trip per evaluation).
-            const unsigned long long want = (unsigned long long)(nevals + 1);
-            if (tid == 0) {
-                double *mine = part + ((nevals & 1) * NEWTON_MAX_SPLIT + wg) * 3;
-                st_agent(mine, acc[0]); st_agent(mine + 1, acc[1]); st_agent(mine + 2, acc[2]);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the sums are out before the tag
-                __hip_atomic_store(tags + wg, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (tid < 64) {
-                long spins = 0;
-                for (;;) {
-                    const unsigned long long tg = (tid < S) ? __hip_atomic_load(tags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
-                    if (__all(tg >= want)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > 20000000L) { if (tid == 0) bc[3] = 1.0; break; }      // bounded: never hang the GPU
-                }
-            }
-            __syncthreads();
-            {   // every slice's partials, one lane per slice; summed by one thread in slice order (bit-reproducible)
-                const double *base = part + (nevals & 1) * NEWTON_MAX_SPLIT * 3;
-                if (tid < S) { gp[0][tid] = ld_agent(base + tid * 3); gp[1][tid] = ld_agent(base + tid * 3 + 1); gp[2][tid] = ld_agent(base + tid * 3 + 2); }
-            }
-            __syncthreads();
-            if (tid == 0) {
-                double tot[3] = {0.0, 0.0, 0.0};
-                for (int w = 0; w < S; ++w) { tot[0] += gp[0][w]; tot[1] += gp[1][w]; tot[2] += gp[2][w]; }
-                bc[0] = tot[0]; bc[1] = tot[1]; bc[2] = tot[2];
-            }
-            __syncthreads();
-            acc[0] = bc[0]; acc[1] = bc[1]; acc[2] = bc[2];
-            if (bc[3] != 0.0) failed = true;
-            __syncthreads();
-        }
-        ++nevals;
-        L = acc[0]; d1 = acc[1]; d2 = acc[2];
     };
 
-    if (tid == 0) bc[3] = 0.0;
-    __syncthreads();
+    auto eval_at = [&](double t, double &L, double &d1, double &d2) {
+        if (SP) fill_exl(t);
+        __syncthreads();
+        if (!SP) {
+            double acc[3] = {0.0, 0.0, 0.0};
+            if (REG) {
+                double f = 0.0, f1 = 0.0, f2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < NEWTON_ROWS; ++i) {
+                    const int row = sub * NEWTON_ROWS + i;
+                    const double xe = xr[i] * sh.exl[row][0], xl = xe * sh.exl[row][1];
+                    f += xe; f1 += xl; f2 += xl * sh.exl[row][1];
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // at most 4 LDS pairs in flight
+                }
+                f = quad_sum(f); f1 = quad_sum(f1); f2 = quad_sum(f2);
+                // the log and the two divisions per pattern are left to the service wave (their temporaries would not
+                // fit beside the 40 sumtable registers at 8 waves per SIMD)
+                if (sub == 0) { sh.fb[0][tid >> 2] = f; sh.fb[1][tid >> 2] = f1; sh.fb[2][tid >> 2] = f2; }
+            } else
+            for (int p = p_begin + tid; p < p_end; p += NEWTON_CWAVES * 64) {
+                const double w = r.weight[p];
+                if (w == 0.0) continue;
+                double f = 0.0, f1 = 0.0, f2 = 0.0;
+#pragma unroll 8
+                for (int row = 0; row < CLV_ROWS; ++row) {
+                    const double xe = r.sumtab[(size_t)row * M + p] * sh.exl[row][0], xl = xe * sh.exl[row][1];
+                    f += xe; f1 += xl; f2 += xl * sh.exl[row][1];
+                }
+                const double r1 = f1 / f;
+                acc[0] += w * (log(f * 0.25) - r.scl[p] * LOG_2_256);
+                acc[1] += w * r1;
+                acc[2] += w * (f2 / f - r1 * r1);
+            }
+            if (!REG) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { const double s = wave_sum(acc[i]); if (lane == 0) sh.red[i][wave] = s; }
+            }
+        }
+        __syncthreads();
+        if (SP) {                            // the workgroup's sums in a fixed order, then the exchange
+            double tot[3];
+            if (REG) {                       // lane l finishes patterns l and 64 + l of the slice
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h) {
+                    const double w = h ? sw1 : sw0, sc = h ? ss1 : ss0;
+                    if (w != 0.0) {
+                        const int j = 64 * h + lane;
+                        const double f = sh.fb[0][j], r1 = sh.fb[1][j] / f;
+                        a0 += w * (log(f * 0.25) - sc * LOG_2_256); a1 += w * r1; a2 += w * (sh.fb[2][j] / f - r1 * r1);
+                    }
+                }
+                tot[0] = wave_sum(a0); tot[1] = wave_sum(a1); tot[2] = wave_sum(a2);
+                tot[0] = __shfl(tot[0], 0); tot[1] = __shfl(tot[1], 0); tot[2] = __shfl(tot[2], 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    double s = sh.red[i][0];
+#pragma unroll
+                    for (int w = 1; w < NEWTON_CWAVES; ++w) s += sh.red[i][w];
+                    tot[i] = s;
+                }
+            }
+            bool bad = false;
+            if (S > 1) {
+                const u64 want = (u64)(nevals + 1);
+                u64 *slot = gran + (size_t)((nevals & 1) * NEWTON_MAX_SPLIT) * 6;
+                if (lane < 6) {              // publish: six granules {tag, half of a double}, one lane each
+                    const int c = lane >> 1;
+                    const u64 bits = (u64)__double_as_longlong(c == 0 ? tot[0] : (c == 1 ? tot[1] : tot[2]));
+                    st_granule(slot + wg * 6 + lane, (want << 32) | ((lane & 1) ? (bits >> 32) : (bits & 0xFFFFFFFFull)));
+                }
+                u64 x[6] = {0, 0, 0, 0, 0, 0};
+                long spins = 0;
+                for (;;) {                   // gather: lane l re-reads slice l's granules until all six carry this evaluation's tag
+                    bool ok = true;
+                    if (lane < S) {
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) { x[k] = ld_granule(slot + lane * 6 + k); ok = ok && (x[k] >> 32) == want; }
+                    }
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > NEWTON_SPIN_LIMIT) { bad = true; break; }      // bounded: never hang the GPU
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {   // lanes >= S contribute +0.0 (exact); fixed shuffle tree: a function of S alone
+                    const u64 bits = ((x[2 * i + 1] & 0xFFFFFFFFull) << 32) | (x[2 * i] & 0xFFFFFFFFull);
+                    tot[i] = wave_sum(lane < S ? __longlong_as_double((long long)bits) : 0.0);
+                }
+            }
+            if (lane == 0) { sh.bc[0] = tot[0]; sh.bc[1] = tot[1]; sh.bc[2] = tot[2]; if (bad) sh.bc[3] = 1.0; }
+        }
+        __syncthreads();
+        if (sh.bc[3] != 0.0) failed = true;
+        ++nevals;
+        L = uni(sh.bc[0]); d1 = uni(sh.bc[1]); d2 = uni(sh.bc[2]);
+    };
+
     double t = r.t0;
     if (r.max_iter > 0) t = t < PML_TMIN ? PML_TMIN : (t > PML_TMAX ? PML_TMAX : t);
+    t = uni(t);
     double L = 0.0, d1 = 0.0, d2 = 0.0, tn = t;
     bool first = true;
     int it = 0, bt = 0;
@@ -625,7 +680,7 @@ __global__ __launch_bounds__(256, 3) void k_newton(const ModelDev *__restrict__ 
         eval_at(tn, Ln, n1, n2);
         if (first) { first = false; L = Ln; d1 = n1; d2 = n2; }
         else {
-            if (!(failed || Ln >= L - 1e-9 || bt >= 8)) { ++bt; tn = 0.5 * (tn + t); tn = tn < PML_TMIN ? PML_TMIN : (tn > PML_TMAX ? PML_TMAX : tn); continue; }
+            if (!(failed || Ln >= L - 1e-9 || bt >= 8)) { ++bt; tn = 0.5 * (tn + t); tn = uni(tn < PML_TMIN ? PML_TMIN : (tn > PML_TMAX ? PML_TMAX : tn)); continue; }
             if (failed || Ln < L - 1e-9) break;
             const double dt = fabs(tn - t);
             t = tn; L = Ln; d1 = n1; d2 = n2; ++it;
@@ -635,36 +690,59 @@ __global__ __launch_bounds__(256, 3) void k_newton(const ModelDev *__restrict__ 
         const double step = (d2 < 0.0) ? -d1 / d2 : (d1 > 0.0 ? t : -0.5 * t);
         tn = t + step; bt = 0;
         const bool tiny = fabs(step) < r.tol && d2 < 0.0;   // converged: take the (sub-tolerance) step unevaluated
-        tn = tn < PML_TMIN ? PML_TMIN : (tn > PML_TMAX ? PML_TMAX : tn);
+        tn = uni(tn < PML_TMIN ? PML_TMIN : (tn > PML_TMAX ? PML_TMAX : tn));
         if (tiny) { t = tn; break; }
     }
-    if (tid == 0 && wg == 0) {
-        if (failed) { t = r.t0; L = __builtin_nan(""); }
+    if (SP && lane == 0 && wg == 0) {
+        if (failed) { t = r.t0; L = __builtin_nan(""); }      // exchange timeout: reported, the host fails the call
         r.out[0] = t; r.out[1] = L; r.out[2] = d1; r.out[3] = d2;
         if (r.t_dev0) { *r.t_dev0 = t; *r.t_dev1 = t; }
     }
     if (r.patlnl != nullptr) {                  // per-pattern lnL at the returned length (every slice its own patterns)
         __syncthreads();
-        if (tid < NCAT * NS) { const double lr = md->eval[tid % NS] * r.rates[tid / NS]; exl[tid][0] = exp(lr * t); exl[tid][1] = lr; }
+        if (SP) fill_exl(t);
         __syncthreads();
-        if (REG) {
-            double f = 0.0;
-#pragma unroll
-            for (int i = 0; i < CLV_ROWS / 2; ++i) f += xr[i] * exl[rhalf * (CLV_ROWS / 2) + i][0];
-            f += lane_swap1(f);
-            const int p = p_begin + (tid >> 1);
-            if (rhalf == 0 && p < p_end) r.patlnl[p] = (rw != 0.0) ? log(f * 0.25) - rscl * LOG_2_256 : 0.0;
-        } else {
-            for (int p = p_begin + tid; p < p_end; p += 256) {
+        if (!SP) {
+            if (REG) {
                 double f = 0.0;
-                if (r.weight[p] != 0.0) {
-                    for (int row = 0; row < CLV_ROWS; ++row) f += r.sumtab[(size_t)row * M + p] * exl[row][0];
-                    f = log(f * 0.25) - r.scl[p] * LOG_2_256;
+#pragma unroll
+                for (int i = 0; i < NEWTON_ROWS; ++i) f += xr[i] * sh.exl[sub * NEWTON_ROWS + i][0];
+                f = quad_sum(f);
+                const int p = p_begin + (tid >> 2);
+                if (sub == 0 && p < p_end) r.patlnl[p] = (rw != 0.0) ? log(f * 0.25) - rscl * LOG_2_256 : 0.0;
+            } else {
+                for (int p = p_begin + tid; p < p_end; p += NEWTON_CWAVES * 64) {
+                    double f = 0.0;
+                    if (r.weight[p] != 0.0) {
+                        for (int row = 0; row < CLV_ROWS; ++row) f += r.sumtab[(size_t)row * M + p] * sh.exl[row][0];
+                        f = log(f * 0.25) - r.scl[p] * LOG_2_256;
+                    }
+                    r.patlnl[p] = f;
                 }
-                r.patlnl[p] = f;
             }
         }
     }
+}
+
+// (the streaming form is a second kernel so that its loads do not cost the register-resident form its 8 waves per
+// SIMD; each kernel skips the other's requests)
+template <bool REG>
+__global__ __launch_bounds__(NEWTON_THREADS, REG ? 8 : 4) void k_newton(const ModelDev *__restrict__ md,
+                                                                        const NewtonReq *__restrict__ reqs) {
+    __shared__ NewtonShared sh;
+    const NewtonReq &r = reqs[blockIdx.y];            // by reference: a private copy would live in scratch (rates[] is indexed dynamically)
+    const int mpad = r.mpad, wg = blockIdx.x;
+    // the split depends on the request alone (not on what else is in the launch): results are reproducible
+    // whatever the batch composition
+    const int S = min(NEWTON_MAX_SPLIT, (mpad + NEWTON_SLICE - 1) / NEWTON_SLICE);
+    if (wg >= S) return;
+    const int slice = ((mpad / 16 + S - 1) / S) * 16;
+    if ((slice <= NEWTON_SLICE) != REG) return;
+    const int p_begin = wg * slice, p_end = min(mpad, p_begin + slice);
+    if (threadIdx.x == 0) sh.bc[3] = 0.0;
+    __syncthreads();
+    if ((threadIdx.x >> 6) == NEWTON_CWAVES) newton_body<REG, true>(md, r, sh, S, wg, p_begin, p_end);
+    else newton_body<REG, false>(md, r, sh, S, wg, p_begin, p_end);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -766,7 +844,7 @@ void launch_reduce(const ReduceReq *reqs, int n, hipStream_t s) {
 }
 void launch_newton(const ModelDev *model, const NewtonReq *reqs, int n, int max_mpad, hipStream_t s) {
     if (n <= 0) return;
-    int S = (max_mpad + 127) / 128;       // grid width; each request uses its own split (k_newton)
+    int S = (max_mpad + NEWTON_SLICE - 1) / NEWTON_SLICE;       // grid width; each request uses its own split (k_newton)
     S = S < 1 ? 1 : (S > NEWTON_MAX_SPLIT ? NEWTON_MAX_SPLIT : S);
     // Not every workgroup of the launch has to be resident at once: workgroups are dispatched in grid order (x
     // fastest, round-robin over the XCDs), so the lowest unfinished request always has all of its <= 64 slices
@@ -774,7 +852,8 @@ void launch_newton(const ModelDev *model, const NewtonReq *reqs, int n, int max_
     const int chunk = 32768;
     for (int off = 0; off < n; off += chunk) {
         const int m = (n - off < chunk) ? n - off : chunk;
-        hipLaunchKernelGGL(k_newton, dim3(S, m), dim3(256), 0, s, model, reqs + off);
+        hipLaunchKernelGGL(k_newton<true>, dim3(S, m), dim3(NEWTON_THREADS), 0, s, model, reqs + off);
+        if (max_mpad > NEWTON_SLICE * NEWTON_MAX_SPLIT) hipLaunchKernelGGL(k_newton<false>, dim3(S, m), dim3(NEWTON_THREADS), 0, s, model, reqs + off);
     }
 }
 

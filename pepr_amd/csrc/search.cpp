@@ -170,33 +170,85 @@ int Batch::nni_round(const std::vector<char> &active, std::vector<double> &lnl, 
     }
     std::vector<std::vector<double>> L(n), Tn(n);
     for (int g = 0; g < n; ++g) { L[g].assign(edges[g].size() * 3, 0.0); Tn[g].assign(edges[g].size() * 3, 0.0); }
-    // one run() per internal edge: the current arrangement and both alternatives are three tails
-    // (slots 0..2) of the same gene; alternative k builds its end CLVs into scratch 2k-2, 2k-1
-    for (size_t step = 0; step < maxsteps / 3; ++step) {
+    // ALL internal edges of the round go into one run() (round 1 issued one launch set per edge index): every edge is
+    // scored against the same tree, so the cached directed messages are shared; per edge the current arrangement and
+    // both alternatives are three Newton tails with pooled sumtables; alternative k builds its end CLVs into scratch
+    // 2k-2, 2k-1 -- a workgroup walks its gene's operations in order and a tail sits right behind the operations it
+    // needs, so the four scratch slots are reused from edge to edge.  The round is cut into chunks of edges only when the
+    // pooled sumtables (3 x 640 B per pattern and edge) would not fit in free HBM.
+    std::vector<size_t> tb(n, 0);                 // bytes of one pooled sumtable (+ scaling counts) of gene g
+    size_t per_edge = 0, need_all = 0, nres_all = 0;
+    for (int g = 0; g < n; ++g) {
+        if (edges[g].empty()) continue;
+        tb[g] = ((size_t)CLV_ROWS * genes[g].aln.mpad * 8 + (size_t)genes[g].aln.mpad * 4 + 255) / 256 * 256;
+        per_edge += 3 * tb[g]; need_all += 3 * tb[g] * edges[g].size(); nres_all += 3 * edges[g].size();
+    }
+    size_t nedge_max = maxsteps / 3, chunk = nedge_max;
+    if (nedge_max > 0) {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipSetDevice(ctx->device));
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        size_t budget = std::max(tailpool_cap, (size_t)(0.6 * (double)(free_b + tailpool_cap)));
+        if (const char *e = std::getenv("PML_NNI_POOL_MB")) budget = (size_t)std::atoll(e) << 20;      // test hook
+        if (need_all > budget) chunk = std::max<size_t>(1, budget / std::max<size_t>(per_edge, 1));
+        if (int rc = ensure_tailpool(std::min(need_all, chunk * per_edge))) return rc;
+        if (int rc = ensure_results(nres_all)) return rc;
+    }
+    for (size_t e0 = 0; e0 < nedge_max; e0 += chunk) {
         ++cnt_nni;
         std::vector<PendingOp> ops; std::vector<Tail> tails;
-        for (int g = 0; g < n; ++g) {
-            if (!active[g] || step >= edges[g].size()) continue;
+        std::vector<int> nneed(n, 0);
+        for (int g = 0; g < n; ++g) {              // every cached message the chunk's edges read
+            if (!active[g]) continue;
             const Tree &T = genes[g].tree;
-            auto [u, v] = edges[g][step];
-            const double t0 = T.len[u][T.slot(u, v)];
-            int a[2], c[2]; double la[2], lc[2];
-            others(T, u, v, a, la); others(T, v, u, c, lc);
-            need(g, u, v, ops); need(g, v, u, ops);
-            need(g, a[0], u, ops); need(g, a[1], u, ops); need(g, c[0], v, ops); need(g, c[1], v, ops);
-            tails.push_back({g, msg(g, u, v), msg(g, v, u), MODE_SUMTABLE, t0, 32, 0, -1});
-            for (int alt = 1; alt <= 2; ++alt) {
-                const int y = (alt == 1) ? 0 : 1, sx = 2 * alt - 2, sy = 2 * alt - 1;
-                PendingOp X; X.gene = g; X.out_kind = SIDE_SCRATCH; X.out_id = sx; X.level = 0;
-                X.child[0] = msg(g, a[0], u); X.t[0] = la[0]; X.child[1] = msg(g, c[y], v); X.t[1] = lc[y];
-                PendingOp Y; Y.gene = g; Y.out_kind = SIDE_SCRATCH; Y.out_id = sy; Y.level = 0;
-                Y.child[0] = msg(g, a[1], u); Y.t[0] = la[1]; Y.child[1] = msg(g, c[1 - y], v); Y.t[1] = lc[1 - y];
-                ops.push_back(X); ops.push_back(Y);
-                tails.push_back({g, {SIDE_SCRATCH, sx}, {SIDE_SCRATCH, sy}, MODE_SUMTABLE, t0, 32, alt, -1});
+            const size_t before = ops.size();
+            for (size_t e = e0; e < std::min(edges[g].size(), e0 + chunk); ++e) {
+                auto [u, v] = edges[g][e];
+                int a[2], c[2]; double la[2], lc[2];
+                others(T, u, v, a, la); others(T, v, u, c, lc);
+                need(g, u, v, ops); need(g, v, u, ops);
+                need(g, a[0], u, ops); need(g, a[1], u, ops); need(g, c[0], v, ops); need(g, c[1], v, ops);
+            }
+            nneed[g] = (int)(ops.size() - before);
+        }
+        size_t pool_off = 0, ri = 0;
+        std::vector<size_t> rbase(n, 0);
+        for (int g = 0; g < n; ++g) {
+            if (!active[g] || e0 >= edges[g].size()) continue;
+            const Tree &T = genes[g].tree;
+            int count = nneed[g];
+            rbase[g] = ri;
+            for (size_t e = e0; e < std::min(edges[g].size(), e0 + chunk); ++e) {
+                auto [u, v] = edges[g][e];
+                const double t0 = T.len[u][T.slot(u, v)];
+                int a[2], c[2]; double la[2], lc[2];
+                others(T, u, v, a, la); others(T, v, u, c, lc);
+                auto pooled = [&](Tail t) {
+                    t.sumtab_dev = reinterpret_cast<double *>(d_tailpool + pool_off); pool_off += tb[g];
+                    t.result_dev = d_chain + 4 * ri; t.result_host = h_chain + 4 * ri; ++ri;
+                    tails.push_back(t);
+                };
+                pooled({g, msg(g, u, v), msg(g, v, u), MODE_SUMTABLE, t0, 32, 0, nneed[g]});
+                for (int alt = 1; alt <= 2; ++alt) {
+                    const int y = (alt == 1) ? 0 : 1, sx = 2 * alt - 2, sy = 2 * alt - 1;
+                    PendingOp X; X.gene = g; X.out_kind = SIDE_SCRATCH; X.out_id = sx; X.level = 0;
+                    X.child[0] = msg(g, a[0], u); X.t[0] = la[0]; X.bv[0] = u; X.bq[0] = T.slot(u, a[0]);
+                    X.child[1] = msg(g, c[y], v); X.t[1] = lc[y]; X.bv[1] = v; X.bq[1] = T.slot(v, c[y]);
+                    PendingOp Y; Y.gene = g; Y.out_kind = SIDE_SCRATCH; Y.out_id = sy; Y.level = 0;
+                    Y.child[0] = msg(g, a[1], u); Y.t[0] = la[1]; Y.bv[0] = u; Y.bq[0] = T.slot(u, a[1]);
+                    Y.child[1] = msg(g, c[1 - y], v); Y.t[1] = lc[1 - y]; Y.bv[1] = v; Y.bq[1] = T.slot(v, c[1 - y]);
+                    ops.push_back(X); ops.push_back(Y); count += 2;
+                    pooled({g, {SIDE_SCRATCH, sx}, {SIDE_SCRATCH, sy}, MODE_SUMTABLE, t0, 32, 0, count});
+                }
             }
         }
         if (int rc = run(ops, tails)) return rc;
-        for (auto &t : tails) { Tn[t.gene][3 * step + t.slot] = res(t.gene, t.slot)[0]; L[t.gene][3 * step + t.slot] = res(t.gene, t.slot)[1]; }
+        for (int g = 0; g < n; ++g) {
+            if (!active[g] || e0 >= edges[g].size()) continue;
+            size_t k = rbase[g];
+            for (size_t e = e0; e < std::min(edges[g].size(), e0 + chunk); ++e)
+                for (int q = 0; q < 3; ++q, ++k) { Tn[g][3 * e + q] = h_chain[4 * k]; L[g][3 * e + q] = h_chain[4 * k + 1]; }
+        }
     }
     // candidate selection and application
     std::vector<std::vector<Cand>> cands(n);

@@ -150,7 +150,10 @@ int main(int argc, char **argv) {
         else return fail(tool, "unknown option " + a);
     }
     if (aln_f.empty() || run.empty()) return fail(tool, "usage: raxmlHPC -f d|e|g -m PROTGAMMAWAG -s aln.phy -n run [-t tree] [-z trees]");
-    if (model_s.find("WAG") == std::string::npos || model_s.compare(0, 4, "PROT") != 0) return fail(tool, "only PROT*WAG* models are built, got " + model_s);
+    // exactly one model is built; PROTGAMMAWAGF (empirical frequencies), PROTCATWAG, PROTGAMMAIWAG and the other 22
+    // matrices -matrix_eval may pass (PhylogenomicPipeline2.java:260-284) are different likelihood functions and are
+    // refused rather than run as WAG under their name
+    if (model_s != "PROTGAMMAWAG") return fail(tool, "only -m PROTGAMMAWAG is built, got " + model_s);
     if (std::ifstream("RAxML_info." + run)) return fail(tool, "RAxML output files with the run ID <" + run + "> already exist");
     if (f == "b") {                                       // RAxMLRunner.java:453-516: draw the bipartition frequencies of -z trees on -t tree (host only)
         if (tree_f.empty() || trees_f.empty()) return fail(tool, "-f b needs -t tree -z trees");

@@ -35,24 +35,52 @@ def shard(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
+def shard_by_cost(costs, rank, world):
+    """static block-cyclic by DESCENDING cost estimate (taxa x patterns).  Item ids sorted by cost
+    (ties by id), dealt round-robin: every rank gets one of the `world` most expensive genes, and so on down."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    return order[rank::world]
+
+
 def _device():
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
 
 
-def gather_results(gene_ids, lnl, alpha=None, tree_length=None, newicks=None, newick_bytes=0, dst=0):
-    """Gathers per-gene records to rank `dst`.  Every rank must hold the same number of genes
-    (pad with gene id -1).  Returns on dst a dict gene_id -> record, elsewhere None."""
+def _world_max(x):
+    """MAX of a small non-negative integer over all ranks (1 element; latency-bound like the gather)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return int(x)
+    t = torch.tensor([float(x)], dtype=torch.float64, device=_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t[0])
+
+
+def gather_results(gene_ids, lnl, alpha=None, tree_length=None, newicks=None, newick_bytes=None, dst=0, status=None):
+    """Gathers per-gene records {gene id, status, lnL, alpha, tree length, Newick} to rank `dst` (ONE gather).
+    Every rank must hold the same number of records (pad with gene id -1).  `status`: per-record PML_* code
+    (default 0).  `newick_bytes`: None/0 = sized by an all-reduce MAX of the longest Newick over all ranks; an explicit
+    size that a Newick does not fit in raises (never truncates silently).  Returns on dst a dict gene_id -> record,
+    elsewhere None."""
     n = len(gene_ids)
+    enc = [(s or "").encode() for s in newicks] if newicks is not None else None
+    if enc is not None:
+        longest = max([len(b) for b in enc], default=0)
+        if not newick_bytes:
+            newick_bytes = (_world_max(longest) + 1 + 7) // 8 * 8
+        elif longest > newick_bytes:
+            raise ValueError("gather_results: a %d-byte Newick does not fit newick_bytes=%d" % (longest, newick_bytes))
+    else:
+        newick_bytes = 0
     width = RECORD_HEADER + (newick_bytes + 7) // 8
     rec = np.zeros((n, width))
     rec[:, 0] = gene_ids
+    rec[:, 1] = status if status is not None else 0.0
     rec[:, 2] = lnl
     rec[:, 3] = alpha if alpha is not None else 0.0
     rec[:, 4] = tree_length if tree_length is not None else 0.0
-    if newicks is not None and newick_bytes:
+    if enc is not None and newick_bytes:
         raw = np.zeros((n, (newick_bytes + 7) // 8 * 8), dtype=np.uint8)
-        for i, s in enumerate(newicks):
-            b = (s or "").encode()[:newick_bytes]
+        for i, b in enumerate(enc):
             raw[i, :len(b)] = np.frombuffer(b, dtype=np.uint8)
         rec[:, RECORD_HEADER:] = raw.view(np.float64)
     if not dist.is_initialized() or dist.get_world_size() == 1:
@@ -78,26 +106,37 @@ def gather_results(gene_ids, lnl, alpha=None, tree_length=None, newicks=None, ne
     return out
 
 
-def jackknife(ctx, genes, reps=100, seed=0, newick_bytes=0, **kw):
+def jackknife(ctx, genes, reps=100, seed=0, newick_bytes=None, **kw):
     """Gene-wise jackknife over all ranks (PhylogenomicPipeline2.java:994-1126 across GPUs): rank r searches the
     replicates r, r+world, ... (pml_jackknife_opts.shard_*; every rank draws the same subsets from `seed`), rank 0
     also searches the full tree; ONE gather of the support trees, then the supports are counted on rank 0.
-    Returns the single-GPU result dict on rank 0, None elsewhere."""
+    A rank whose engine call fails still joins the gather (status < 0 in its records) so that nobody hangs; the
+    failure is then raised on that rank and on rank 0.  Returns the single-GPU result dict on rank 0, None elsewhere."""
     from . import engine
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    part = ctx.jackknife(genes, reps=reps, seed=seed, shard=(rank, world), **kw)
+    err = None
+    try:
+        part = ctx.jackknife(genes, reps=reps, seed=seed, shard=(rank, world), **kw)
+    except Exception as e:              # noqa: BLE001 -- reported through the gather, re-raised below
+        if world == 1:
+            raise
+        err, part = e, {"newick": None, "support_trees": []}
     if world == 1:
         return part
     mine = part["support_trees"]
     per = (reps + world - 1) // world
-    if not newick_bytes:
-        ntax = len({t for g in genes for t in g[0]})
-        newick_bytes = 64 * ntax + 64
-    ids = [rank + world * i if i < len(mine) else -1 for i in range(per)]
-    recs = gather_results(ids, np.zeros(per), newicks=mine + [""] * (per - len(mine)), newick_bytes=newick_bytes)
+    nmine = len(range(rank, reps, world))
+    ids = [rank + world * i if i < nmine else -1 for i in range(per)]
+    st = [(-5 if err is not None else 0) if i < nmine else 0 for i in range(per)]
+    recs = gather_results(ids, np.zeros(per), newicks=(mine + [""] * per)[:per], newick_bytes=newick_bytes, status=st)
+    if err is not None:
+        raise err
     if rank != 0:
         return None
+    bad = sorted(i for i in recs if recs[i]["status"] != 0)
+    if bad:
+        raise RuntimeError("jackknife: replicates %s failed on their rank (status %d)" % (bad[:8], recs[bad[0]]["status"]))
     sup = [recs[i]["newick"] for i in sorted(recs)]
     import re
     plain = re.sub(r"\)\d+:", "):", part["newick"])

@@ -48,10 +48,14 @@ class SequenceAlignment:
 
 
 def _model_from_matrix(matrix):
-    """RAxML -m strings PEPR passes (RAxMLRunner.java:115-132).  Only the WAG family is built."""
+    """RAxML -m strings PEPR passes (RAxMLRunner.java:115-132; the 23 names of -matrix_eval,
+    PhylogenomicPipeline2.java:260-284).  Exactly ONE model is built -- PROTGAMMAWAG (WAG exchangeabilities, RAxML's
+    fixed 3-decimal WAG frequencies, GAMMA with 4 mean-rate categories) -- and nothing else is ever run under another
+    model's name: PROTGAMMAWAGF (empirical frequencies), PROTCATWAG, PROTGAMMAIWAG and the other matrices raise."""
     m = (matrix or "PROTGAMMAWAG").upper()
-    if not m.startswith("PROT") or "WAG" not in m:
-        raise ValueError("only PROT{GAMMA,CAT}WAG[F] is implemented on the GPU engine, got %r" % matrix)
+    if m != "PROTGAMMAWAG":
+        raise ValueError("the GPU engine implements PROTGAMMAWAG only; %r is not built (it would be a different "
+                         "likelihood function, not a variant spelling)" % matrix)
     return {"ncat": 4, "pi_mode": engine.PI_RAXML_3DP}
 
 
@@ -112,9 +116,9 @@ class RAxMLRunner:
 
     def run(self):
         """-f d (ML search) or, with setPerSiteLogLikelihoods(true), -f g on the given trees."""
+        mdl = _model_from_matrix(self.matrix)          # an unbuilt model name is refused, loudly, before any device work
         ctx = self.ctx or default_context()
         try:
-            mdl = _model_from_matrix(self.matrix)
             gene = self.alignment.as_gene()
             if self.perSiteLL:
                 self.perSiteLLs = []

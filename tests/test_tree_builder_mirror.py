@@ -15,6 +15,15 @@ def test_dispatch_and_errors_cpu():
     with pytest.raises(ValueError):
         tb._model_from_matrix("GTRGAMMA")
     assert tb._model_from_matrix("PROTGAMMAWAG")["ncat"] == 4
+    # -matrix_eval (PhylogenomicPipeline2.java:260-284) compares lnL across model names: a name that is not built must
+    # never be run as plain WAG under its label
+    for other in ("PROTGAMMAWAGF", "PROTCATWAG", "PROTGAMMAIWAG", "PROTGAMMALGF", "PROTGAMMAJTT", "PROTMIXWAG"):
+        with pytest.raises(ValueError):
+            tb._model_from_matrix(other)
+    r = tb.RAxMLRunner()
+    r.setAlignment(tb.SequenceAlignment(["a", "b", "c"], ["AR", "AR", "AQ"])); r.setMatrix("PROTGAMMAWAGF")
+    with pytest.raises(ValueError):
+        r.run()                                   # refused before anything touches the device
     b.setBootstrapReps(0); assert b.getBootstrapReps() == 0
     b.setRunName("x"); assert b.getRunName() == "x"
     b.setTreeString("(a,b,c);"); assert b.getTreeString() == "(a,b,c);"
