@@ -5,12 +5,18 @@ Step = one full pass of the hot path over one batch: for every gene, transition 
 branches, the complete post-order CLV pass (newview), root evaluation and the weighted lnL
 reduction -- inputs (encoded alignments, trees) already resident in HBM.
 
-Workload (weak scaling, genes sharded over ranks, no data-path collective):
+Workload (genes sharded over ranks, no data-path collective):
   c3 (default): BASELINE config[2], 128 genes x (50 taxa x 1000 AA sites) per GPU, WAG+G4, f64
   c4:           BASELINE config[3] shard, 63 genes x (200 x 5000) per GPU (500 genes / 8 GPUs)
+  --scaling weak (default): the per-GPU gene count is fixed as N grows;
+  --scaling strong: a FIXED gene list (--genes, default 500 for c4 = BASELINE config[3] itself, 128 for c3) is dealt
+                    over the N ranks block-cyclically by descending cost; a rank whose share does not fit in
+                    HBM at once scores it in consecutive resident sub-batches.
 `value` = M site-lnL/s = 1e-6 x alignment patterns x full-tree likelihood evaluations per second,
-summed over all ranks.  Launch: python bench.py --gpus N --steps K --warmup W  (N>1 through
-torch.distributed.run, one rank per GPU).
+summed over all ranks.  Launch: python bench.py --gpus N --steps K --warmup W.  With N > 1 and no
+WORLD_SIZE in the environment this process only SPAWNS the N ranks (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*
+set) before anything touches the GPU and exits with their code; under torch.distributed.run the ranks come from the
+environment and --gpus must equal WORLD_SIZE.
 """
 import argparse
 import json
@@ -76,6 +82,64 @@ def cpu_baseline(genes, alpha, budget_s=12.0):
     return out
 
 
+class _Trees:
+    """result trees of a one-shot search, with the two methods bench uses of a resident batch"""
+    def __init__(self, nw):
+        self.nw = nw
+
+    def newick(self, i):
+        return self.nw[i]
+
+    def close(self):
+        pass
+
+
+def launch_ranks(ngpus):
+    """Parent of `python bench.py --gpus N` (N > 1, no WORLD_SIZE): starts one child per GPU with the torch.distributed
+    environment and waits.  It never imports torch or touches the GPU, and nothing is exec'ed from a GPU process."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(ngpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:                          # a rank that dies would leave the others waiting in a collective: stop them
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = rc or code
+                for q in live:
+                    q.terminate()
+    return rc
+
+
+def plumbing_only(world_expected):
+    """BENCH_PLUMBING_ONLY=1 (CPU rehearsal of the N > 1 path, tests/test_distributed_gloo.py): ranks, sharding and the
+    one gather run for real over gloo, the engine is not touched.  Prints the same JSON shape with n_gpus."""
+    import numpy as np
+    from pepr_amd import distributed as pd
+    rank, local, world = pd.init_from_env("gloo")
+    ids = pd.shard_by_cost([1000] * 13, rank, world)
+    per = (13 + world - 1) // world
+    pad = ids + [-1] * (per - len(ids))
+    out = pd.gather_results(pad, np.array([-100.0 - i for i in pad]), newicks=["(a:%d,b:1,c:1);" % i for i in pad],
+                            status=[0] * per)
+    if rank == 0:
+        ok = sorted(out) == list(range(13)) and all(out[i]["lnl"] == -100.0 - i and out[i]["status"] == 0 for i in out)
+        print(json.dumps({"metric": "plumbing only", "n_gpus": world, "genes_total": 13, "gathered": len(out), "ok": bool(ok)}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier(); dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,7 +148,20 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c4", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true", help="skip the gene-trees/s leg (NJ + NNI search of every gene)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--genes", type=int, default=0, help="strong scaling: total genes of the job (default 500 for c4, 128 for c3, 16 for tiny)")
     args = ap.parse_args()
+
+    # N ranks: either torch.distributed.run provides them (WORLD_SIZE set) or this process starts them itself, strictly
+    # before any GPU call
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args.gpus))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ["WORLD_SIZE"]), file=sys.stderr)
+        sys.exit(2)
+    if os.environ.get("BENCH_PLUMBING_ONLY"):
+        sys.exit(plumbing_only(args.gpus))
 
     import numpy as np
     import torch
@@ -96,11 +173,16 @@ def main():
     rank, local, world = pd.init_from_env(os.environ.get("BENCH_BACKEND"))
     if "BENCH_FORCE_DEVICE" in os.environ:
         local = int(os.environ["BENCH_FORCE_DEVICE"])
-    if world != args.gpus and world > 1:
-        args.gpus = world
     ntax, nsites, per_gpu = {"c3": (50, 1000, 128), "c4": (200, 5000, 63), "tiny": (12, 200, 8)}[args.workload]
     alpha = 0.8
-    gene_ids = [rank * per_gpu + i for i in range(per_gpu)]            # contiguous shard of the global list
+    strong = args.scaling == "strong"
+    if strong:
+        total = args.genes or {"c3": 128, "c4": 500, "tiny": 16}[args.workload]
+        gene_ids = pd.shard_by_cost([ntax * nsites] * total, rank, world)   # synthetic genes: equal estimates -> round robin
+        per_gpu = (total + world - 1) // world
+    else:
+        total = per_gpu * world
+        gene_ids = [rank * per_gpu + i for i in range(per_gpu)]            # contiguous shard of the global list
     genes = [synth.simulate_alignment(ntax, nsites, 1 + gid, alpha) for gid in gene_ids]
     # CPU baseline first (rank 0, N=1 only): worker processes are spawned before this process
     # touches the GPU
@@ -111,30 +193,48 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     torch.cuda.set_device(local)
     ctx = engine.Context(local, profile=True)
-    batch = engine.Batch(ctx, [(g[0], g[1]) for g in genes], [g[2] for g in genes], alpha=alpha)
-    npat = sum(batch.npatterns())
-
-    def step():
-        lnl = batch.score()
-        if world > 1:                      # the one gather of per-gene results (RCCL over xGMI)
-            pd.gather_results(gene_ids, lnl)
-        return lnl
-
-    for _ in range(args.warmup):
-        lnl = step()
-    ctx.kernel_stats(reset=True)
+    # resident sub-batches: the rank's genes are scored from HBM-resident batches; a share that does not fit at once
+    # (strong scaling at small N: 500 C4 genes = 950 GB of CLVs) goes through in consecutive resident sub-batches, every
+    # rank the same number of them so that the barriers pair up; the default workloads are ONE sub-batch
+    free_b = torch.cuda.mem_get_info()[0]
+    gene_bytes = (3 * ntax + 12) * 640 * (nsites + 32)
+    nchunks = max(1, -(-len(genes) * gene_bytes // int(0.8 * free_b)))
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        lnl = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+        nchunks = pd._world_max(nchunks)
+    chunks = [list(c) for c in np.array_split(np.arange(len(genes)), nchunks)]
+    dt, npat, lnl_all = 0.0, 0, []
+    stats = None
+    for ci, idx in enumerate(chunks):
+        sub = [genes[i] for i in idx]
+        batch = engine.Batch(ctx, [(g[0], g[1]) for g in sub], [g[2] for g in sub], alpha=alpha) if sub else None
+        npat += sum(batch.npatterns()) if batch else 0
+        ids = [gene_ids[i] for i in idx] + [-1] * (len(chunks[0]) - len(idx))     # equal record counts per rank
+
+        def step():
+            lnl = batch.score() if batch else np.zeros(0)
+            if world > 1:                      # the one gather of per-gene results (RCCL over xGMI)
+                pd.gather_results(ids, np.concatenate([lnl, np.zeros(len(ids) - len(lnl))]))
+            return lnl
+
+        for _ in range(args.warmup):
+            lnl = step()
+        if ci == 0:
+            ctx.kernel_stats(reset=True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            lnl = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt += time.perf_counter() - t0
+        lnl_all.append(lnl)
+        if batch:
+            batch.close()
     stats = ctx.kernel_stats()
-    assert np.all(np.isfinite(lnl))
+    assert np.all(np.isfinite(np.concatenate(lnl_all)))
 
     tot_pat = npat
     if world > 1:
@@ -157,9 +257,13 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            b = engine.Batch(sctx, G, None, alpha=1.0)
-            tset = time.perf_counter() - t0
-            l, _ = b.search(True, True, 0, 1e-3)
+            if nchunks > 1:                 # does not fit at once: the one-shot call walks it in HBM-sized sub-batches
+                out = sctx.search(G, None, nni=True, spr_radius=0, epsilon=1e-3)
+                b, tset, l = _Trees([o["newick"] for o in out]), 0.0, np.array([o["lnl"] for o in out])
+            else:
+                b = engine.Batch(sctx, G, None, alpha=1.0)
+                tset = time.perf_counter() - t0
+                l, _ = b.search(True, True, 0, 1e-3)
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
@@ -189,15 +293,15 @@ def main():
             if world > 1:
                 t = torch.tensor([tspr], dtype=torch.float64, device=pd._device())
                 dist.all_reduce(t, op=dist.ReduceOp.MAX); tspr = float(t[0])
-            spr = {"gene_trees_per_sec": per_gpu * world / tspr, "seconds": tspr,
+            spr = {"gene_trees_per_sec": total / tspr, "seconds": tspr,
                    "algorithm": "randomised stepwise-addition parsimony start + model optimisation + NNI + lazy SPR (radius 5), eps 1e-3",
                    "rf_to_generating_tree_mean_rank0": float(np.mean([engine.rf_distance(genes[i][2], sout[i]["newick"]) for i in range(len(genes))]))}
         sctx.close()
         if world > 1:
             t = torch.tensor([sdt, cold], dtype=torch.float64, device=pd._device())
             dist.all_reduce(t, op=dist.ReduceOp.MAX); sdt, cold = float(t[0]), float(t[1])
-        search = {"gene_trees_per_sec": per_gpu * world / sdt, "seconds": sdt, "setup_seconds_rank0": tc,
-                  "cold_first_call_seconds": cold, "cold_gene_trees_per_sec": per_gpu * world / cold, "genes": per_gpu * world,
+        search = {"gene_trees_per_sec": total / sdt, "seconds": sdt, "setup_seconds_rank0": tc,
+                  "cold_first_call_seconds": cold, "cold_gene_trees_per_sec": total / cold, "genes": total,
                   "algorithm": "NJ start + WAG+G4 model optimisation + NNI hill climbing (eps 1e-3); timed from host char rows to Newick",
                   "rf_to_generating_tree_mean_rank0": float(np.mean(rf)), "finite": bool(np.all(np.isfinite(slnl))),
                   # no closed form for a search -> measured call counts x the per-pattern byte figures / time
@@ -209,21 +313,30 @@ def main():
         nv = stats["newview"]
         avg_ms = nv["ms"] / max(nv["launches"], 1)
         achieved = nv["algo_bytes"] / max(nv["launches"], 1) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.workload)
-        if os.path.exists(pmc):       # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
-            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
+        # HBM bytes per launch: rocprofv3 --pmc cannot run inside this process, so this is the COMMITTED counter
+        # measurement of this same command (profiles/, named in traffic_source), not a value measured in this run
+        traffic, traffic_src = None, None
+        for name in ("r02_pmc_traffic_%s.json" % args.workload, "r01_pmc_traffic_%s.json" % args.workload):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc) and not strong:
+                traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
+                traffic_src = "committed PMC passes, profiles/" + name
+                break
         out = {
             "metric": "M site-lnL/sec (WAG+G4 full-tree likelihood evaluations x alignment patterns); the gene-trees/sec half of BASELINE.json's metric is search.gene_trees_per_sec",
             "value": tot_pat * args.steps / dt / 1e6, "unit": "M site-lnL/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %d genes/GPU x %d taxa x %d AA sites, WAG+G4 (RAxML PROTGAMMAWAG conventions), seeds 1..G" % (
-                args.workload, per_gpu, ntax, nsites), "patterns_per_gpu": npat, "genes_total": per_gpu * world,
+            "config": {"workload": "%s: %s x %d taxa x %d AA sites, WAG+G4 (RAxML PROTGAMMAWAG conventions), seeds 1..G" % (
+                args.workload, ("%d genes in all, block-cyclic by cost" % total) if strong else ("%d genes/GPU" % per_gpu), ntax, nsites),
+                "patterns_rank0": npat, "genes_total": total, "resident_sub_batches_per_rank": nchunks,
                 "parallelism": "gene-sharded x%d" % world},
+            # frac = SURVEY 8d algorithmic bytes / time / peak (counts CLVs that virtual cherries and pitchforks never
+            # materialise); frac_traffic = counter bytes / time / peak = the share of the HBM peak the kernel really streams
             "roofline": {"bound": "hbm", "kernel": "k_oplist (newview+evaluate)", "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac_traffic": (traffic / (avg_ms * 1e-3) / 8e12) if (traffic and avg_ms > 0) else None,
                          "avg_launch_ms": avg_ms, "algo_bytes_per_launch": nv["algo_bytes"] / max(nv["launches"], 1)},
             "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in stats.items() if v["launches"]},
         }
@@ -234,7 +347,7 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    batch.close(); ctx.close()
+    ctx.close()
     if world > 1:
         dist.destroy_process_group()
 
