@@ -330,6 +330,7 @@ int Batch::create_replicates(Ctx *c, const GeneStore &store, const std::vector<s
 }
 
 int Batch::chain_sync() {
+    if (int rc = flush_deferred()) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream2));
     HIPCHK(hipGetLastError());
@@ -367,7 +368,7 @@ int Batch::chain_begin(size_t nresults) {
     // descriptors of the whole pass stay in the staging ring until the final sync: ~4 KB per (gene, step) is what
     // run() reserves (it sizes for the worst case of 10 matrix requests per operation)
     if (int rc = ensure_stage(std::min<size_t>(nresults * 4096 + (1 << 20), (size_t)256 << 20))) return rc;
-    chain = true; chain_off = 0;
+    chain = true; chain_off = 0; flush_quota = 1;
     return 0;
 }
 int Batch::ensure_stage(size_t bytes) {
@@ -504,6 +505,46 @@ int Batch::need(int g, int v, int to, std::vector<PendingOp> &ops) {
 // ------------------------------------------------------------------------------------------
 static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// one upload for all deferred steps (their descriptors are consecutive in the staging ring), then their launches in order
+int Batch::flush_deferred() {
+    if (deferred.empty()) return 0;
+    const size_t lo = deferred.front().base, hi = deferred.back().base + deferred.back().bytes;
+    const hipStream_t cs = deferred.front().lane ? ctx->stream2 : ctx->stream;
+    HIPCHK(hipMemcpyAsync((char *)d_stage + lo, (char *)h_stage + lo, hi - lo, hipMemcpyHostToDevice, cs));
+    const ModelDev *md = ctx->d_model[pi_mode];
+    for (const Deferred &L : deferred) {
+        const hipStream_t st = L.lane ? ctx->stream2 : ctx->stream;
+        double *const frags_buf = L.lane ? d_frags2 : d_frags;
+        char *ds = (char *)d_stage + L.base;
+        ctx->tic_stream = st;
+        if (L.nreq) {
+            ctx->tic(K_PMAT, (double)L.nreq * PFRAG * 8);
+            launch_pmat(md, (const PmatReq *)(ds + L.o_req), frags_buf, (int)L.nreq, st);
+            ctx->toc();
+        }
+        if (L.nruns) {
+            ctx->tic(K_NEWVIEW, L.algo_bytes);
+            launch_oplist((const NvOp *)(ds + L.o_ops), (const GeneRun *)(ds + L.o_runs), (int)L.nruns, L.max_mpad, L.any_pitch, st);
+            ctx->toc();
+        }
+        if (L.stagger) hipEventRecord(ev_stagger, st);
+        if (L.neval) {
+            ctx->tic(K_REDUCE, 0);
+            launch_reduce((const ReduceReq *)(ds + L.o_red), (int)L.neval, st);
+            ctx->toc();
+        }
+        if (L.nnewton) {
+            ctx->tic(K_NEWTON, L.newton_bytes);
+            launch_newton(md, (const NewtonReq *)(ds + L.o_newt), (int)L.nnewton, L.newton_maxm, st);
+            ctx->toc();
+        }
+        ctx->tic_stream = nullptr;
+    }
+    deferred.clear();
+    flush_quota = std::min<size_t>(flush_quota * 2, 8);
+    return 0;
 }
 
 int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
@@ -721,31 +762,20 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     }
 
     if (req_overflow) return ctx->fail(-5, "internal: transition-matrix request bound exceeded");
-    HIPCHK(hipMemcpyAsync(ds, hs, bytes, hipMemcpyHostToDevice, st));
-    const ModelDev *md = ctx->d_model[pi_mode];
-    if (ireq) {
-        ctx->tic(K_PMAT, (double)ireq * PFRAG * 8);
-        launch_pmat(md, (const PmatReq *)(ds + o_req), frags_buf, (int)ireq, st);
-        ctx->toc();
-    }
-    if (nruns) {
-        ctx->tic(K_NEWVIEW, algo_bytes);
-        launch_oplist((const NvOp *)(ds + o_ops), (const GeneRun *)(ds + o_runs), (int)nruns, max_mpad, any_pitch, st);
-        ctx->toc();
-    }
-    if (record_stagger) { record_stagger = false; hipEventRecord(ev_stagger, st); }
-    if (neval) {
-        ctx->tic(K_REDUCE, 0);
-        launch_reduce((const ReduceReq *)(ds + o_red), (int)neval, st);
-        ctx->toc();
-    }
-    if (nnewton) {
-        double nb = 0;
-        for (auto &t : tails) if (t.mode != MODE_EVALUATE) nb += (double)genes[t.gene].aln.npat * 640;
-        ctx->tic(K_NEWTON, nb);
-        launch_newton(md, (const NewtonReq *)(ds + o_newt), (int)nnewton, newton_maxm, st);
-        ctx->toc();
-    }
+    double newton_bytes = 0;
+    for (auto &t : tails) if (t.mode != MODE_EVALUATE) newton_bytes += (double)genes[t.gene].aln.npat * 640;
+    Deferred L;
+    L.base = base; L.bytes = bytes; L.o_req = o_req; L.o_ops = o_ops; L.o_runs = o_runs; L.o_red = o_red; L.o_newt = o_newt;
+    L.nreq = ireq; L.nruns = nruns; L.neval = neval; L.nnewton = nnewton; L.max_mpad = max_mpad; L.newton_maxm = newton_maxm;
+    L.any_pitch = any_pitch; L.algo_bytes = algo_bytes; L.newton_bytes = newton_bytes; L.lane = lane; L.stagger = record_stagger;
+    record_stagger = false;
+    // Inside a chained pass the upload + launches of a step are DEFERRED and issued in groups (1, 2, 4, 8, 8, ... steps):
+    // a host-to-device copy between two kernels of one stream costs a ~20 us bubble on the compute queue (measured:
+    // 2866 newton -> pmat gaps of 21 us in a C3 search, profiles/r02b), one copy per group leaves a handful per pass.
+    // The host keeps building the next group while the device works on the last one.
+    deferred.push_back(L);
+    const bool defer = chain && !lanes_active;
+    if (!defer || deferred.size() >= flush_quota) { if (int rc = flush_deferred()) return rc; }
     ctx->tic_stream = nullptr;
     const double t_launched = now_ms();
     ctx->stats[K_HOST_BUILD].launches++; ctx->stats[K_HOST_BUILD].ms += t_launched - t_begin;
@@ -929,6 +959,7 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
     static const bool lanes_on = std::getenv("PML_LANES") != nullptr;
     int nact = 0; for (int g = 0; g < n; ++g) nact += active[g] && !order[g].empty();
     const bool two_lanes = chain && lanes_on && nact >= 16;
+    lanes_active = two_lanes;
     for (size_t step = 0; step < maxlen; ++step) {
         ++cnt_smooth;
         const size_t first = done.size();
@@ -981,7 +1012,7 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
         const double t0 = now_ms();
         if (int rc = chain_sync()) { chain = false; return rc; }
         ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += now_ms() - t0;
-        chain = false;
+        chain = false; lanes_active = false;
         for (auto &d : done) if (!std::isfinite(h_chain[4 * d.idx + 1]))
             return ctx->fail(-5, "k_newton: cross-workgroup exchange timed out (non-finite result)");
         for (auto &d : done) {

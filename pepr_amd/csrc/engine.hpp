@@ -130,6 +130,11 @@ struct Batch {
     bool chain = false; size_t chain_off = 0;
     double *d_lenpool = nullptr;
     double *d_chain = nullptr, *h_chain = nullptr; size_t chain_cap = 0;     // 4 doubles per chained Newton result
+    // a step of a chained pass whose upload + launches are issued later, grouped with its neighbours (flush_deferred)
+    struct Deferred { size_t base, bytes, o_req, o_ops, o_runs, o_red, o_newt, nreq, nruns, neval, nnewton;
+                      int max_mpad, newton_maxm, lane; bool any_pitch, stagger; double algo_bytes, newton_bytes; };
+    std::vector<Deferred> deferred; size_t flush_quota = 1; bool lanes_active = false;
+    int flush_deferred();
     int chain_begin(size_t nresults);
     int ensure_results(size_t nresults);   // h_chain / d_chain: 4 mapped doubles per pooled Newton result
     // pooled sumtables for launches that carry more Newton requests per gene than MAXTAIL (all edges of an NNI round)

@@ -1,0 +1,91 @@
+"""Tree SEARCH at the sizes BASELINE.json names for the multi-GPU configurations (run with -m gpu):
+configs[3] = 200 taxa x 5000 sites (one GPU's work there is a shard of such genes) and configs[4] = 500 taxa x 2000
+sites with 20 % of the taxa absent per gene, NNI + SPR.  Round 1 only SCORED one gene of each size.
+
+The CPU oracle cannot finish a search at these sizes in test time, so the full-size cases assert what the domain offers
+(determinism, independence from HBM sub-batching, the returned tree + alpha re-scores to the returned lnL, the search
+ends at or above the optimised GENERATING tree, Robinson-Foulds distance to the generating tree) and a reduced shape
+(60 x 600, same code path: parsimony start, NNI, lazy SPR radius 5) is compared with the oracle move for move.
+Reference call being replaced: `raxmlHPC -f d -m PROTGAMMAWAG` (RAxMLRunner.java:115-147)."""
+import numpy as np
+import pytest
+
+from pepr_amd import synth
+from util import prune_newick, rf_collapsed
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_batch(ctx, genes, out, min_better, max_mean_rf):
+    from pepr_amd import engine
+    G = [(g[0], g[1]) for g in genes]
+    # (1) the returned Newick + alpha ARE the returned likelihood (score-only path, fresh batch)
+    for g, o in zip(G, out):
+        r = ctx.score([g], [o["newick"]], alpha=o["alpha"])[0]
+        assert abs(r["lnl"] - o["lnl"]) <= 1e-9 * abs(o["lnl"]), (r["lnl"], o["lnl"])
+    # (2) at or above the generating topology with optimised lengths and alpha
+    true = ctx.optimize(G, [g[2] for g in genes], alpha=1.0, epsilon=1e-3)
+    diff = np.array([o["lnl"] - t["lnl"] for o, t in zip(out, true)])
+    assert (diff > -0.05).sum() >= min_better, diff
+    assert diff.min() > -5.0, diff
+    # (3) topology: few differences to the generating tree (branches at the lower length bound are unresolved)
+    rf = [rf_collapsed(g[2], o["newick"]) for g, o in zip(genes, out)]
+    assert np.mean(rf) <= max_mean_rf, rf
+    assert all(engine.rf_distance(g[2], o["newick"]) >= 0 for g, o in zip(genes, out))     # same leaf sets, parsable
+    return diff, rf
+
+
+def test_c4_shard_search_nni_spr(gpu_ctx, monkeypatch):
+    """8 genes of BASELINE configs[3] (200 taxa x 5000 AA sites, seeds 1..8 as bench.py --workload c4):
+    randomised stepwise-addition parsimony start + model optimisation + NNI + lazy SPR radius 5, one batched call."""
+    genes = [synth.simulate_alignment(200, 5000, 1 + i, 0.8) for i in range(8)]
+    G = [(g[0], g[1]) for g in genes]
+    out = gpu_ctx.search(G, None, nni=True, spr_radius=5, epsilon=1e-3, seed=12345)
+    diff, rf = _check_batch(gpu_ctx, genes, out, min_better=7, max_mean_rf=2.0)
+    # the same call in HBM sub-batches (3 genes at a time: one 200 x 5000 gene holds ~2 GB of CLVs): the identical
+    # inference, bit for bit -- determinism and independence from the batch composition in one
+    monkeypatch.setenv("PML_HBM_BUDGET_MB", "7000")
+    again = gpu_ctx.search(G, None, nni=True, spr_radius=5, epsilon=1e-3, seed=12345)
+    for a, b in zip(out, again):
+        assert a["newick"] == b["newick"] and a["lnl"] == b["lnl"] and a["alpha"] == b["alpha"]
+    print("C4 shard: lnL - lnL(optimised generating tree) =", np.round(diff, 3), "collapsed RF =", rf)
+
+
+def _c5_gene(seed, ntax=500, nsites=2000, absent=0.2):
+    """one C5-shaped gene: simulated on `ntax` taxa, then `absent` of them (another subset for every gene) are missing from
+    the gene's alignment, as single-copy gene families miss genomes (PhylogenomicPipeline2.java:564-605 keeps sets with
+    >= min_taxa members); the reference tree is the generating tree induced on the taxa present"""
+    names, rows, nw = synth.simulate_alignment(ntax, nsites, seed, 0.8)
+    rng = np.random.default_rng(seed + 77)
+    keep = sorted(rng.choice(ntax, size=int(round(ntax * (1 - absent))), replace=False))
+    kn = [names[i] for i in keep]
+    return kn, [rows[i] for i in keep], prune_newick(nw, kn)
+
+
+def test_c5_shaped_search_nni_spr(gpu_ctx, monkeypatch):
+    """3 genes of BASELINE configs[4] shape (500 taxa x 2000 sites, 20 % of the taxa absent -> 400 present), NNI + lazy SPR
+    radius 5 from the NJ start; the second run is forced through one-gene HBM sub-batches"""
+    genes = [_c5_gene(9100 + i) for i in range(3)]
+    assert all(len(g[0]) == 400 for g in genes)
+    G = [(g[0], g[1]) for g in genes]
+    out = gpu_ctx.search(G, None, nni=True, spr_radius=5, epsilon=1e-3)
+    diff, rf = _check_batch(gpu_ctx, genes, out, min_better=2, max_mean_rf=6.0)
+    monkeypatch.setenv("PML_HBM_BUDGET_MB", "3000")         # one 400 x 2000 gene needs ~1.6 GB
+    again = gpu_ctx.search(G, None, nni=True, spr_radius=5, epsilon=1e-3)
+    for a, b in zip(out, again):
+        assert a["newick"] == b["newick"] and a["lnl"] == b["lnl"] and a["alpha"] == b["alpha"]
+    print("C5 shape: lnL - lnL(optimised generating tree) =", np.round(diff, 3), "collapsed RF =", rf)
+
+
+def test_reduced_shape_search_vs_oracle(gpu_ctx, oracle_lib):
+    """60 taxa x 600 sites: the same search (given start tree = the engine's parsimony tree, NNI + SPR radius 5) in the
+    CPU oracle and on the device -- same tree (RF 0 over resolved branches) and |dlnL| < 1e-3, the north star's bar"""
+    po = oracle_lib
+    names, rows, nw = synth.simulate_alignment(60, 600, 4242, 0.8)
+    start = gpu_ctx.parsimony([(names, rows)], seed=12345)[0]["newick"]
+    o = gpu_ctx.search([(names, rows)], [start], nni=True, spr_radius=5, epsilon=1e-3)[0]
+    a = po.Alignment(names, rows); e = po.Engine(a, po.Model(0), 4, 1.0)
+    ref_lnl, tree = e.search(po.Tree(start, a), 5, 1e-3)
+    assert abs(o["lnl"] - ref_lnl) < 1e-3, (o["lnl"], ref_lnl)
+    assert rf_collapsed(o["newick"], tree.newick(12)) == 0
+    assert abs(o["alpha"] - e.alpha) < 1e-3 * max(1.0, e.alpha)

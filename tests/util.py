@@ -149,3 +149,36 @@ def fitch_length(names, rows, newick):
         return cur
     down(parse_newick(newick))
     return total
+
+
+def prune_newick(nw, keep):
+    """The tree induced on the leaf set `keep` (degree-2 nodes suppressed, their branch lengths added), as an unrooted
+    Newick with a trifurcation at the top: what a gene that lacks some taxa can at best recover of the generating tree."""
+    keep = set(keep)
+
+    def rec(nd):
+        kids, name, length = nd
+        if not kids:
+            return (([], name, length) if name in keep else None)
+        sub = [x for x in (rec(k) for k in kids) if x is not None]
+        if not sub:
+            return None
+        if len(sub) == 1:
+            return (sub[0][0], sub[0][1], sub[0][2] + length)
+        return (sub, "", length)
+
+    def fmt(nd):
+        kids, name, length = nd
+        return ("(" + ",".join(fmt(k) for k in kids) + ")" if kids else name) + ":%.8f" % length
+
+    t = rec(parse_newick(nw))
+    kids = list(t[0])
+    while len(kids) == 2:                    # rooted binary top -> unrooted trifurcation
+        a, b = kids
+        if a[0]:
+            kids = list(a[0]) + [(b[0], b[1], b[2] + a[2])]
+        elif b[0]:
+            kids = [(a[0], a[1], a[2] + b[2])] + list(b[0])
+        else:
+            break
+    return "(" + ",".join(fmt(k) for k in kids) + ");"
