@@ -563,9 +563,9 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         std::vector<char> seen(genes.size(), 0);
         size_t keyed = 0, loose = 0;
         for (auto &o : ops) { if (!seen[o.gene]) { seen[o.gene] = 1; keyed += 5 * (size_t)genes[o.gene].aln.ntax; }
-                              if (o.out_kind != SIDE_MSG && (o.bv[0] < 0 || o.bv[1] < 0)) loose += 10; }
+                              if (o.out_kind != SIDE_MSG) loose += (o.bv[0] < 0) + (o.bv[1] < 0); }      // one fragment set per child whose length is no tree branch
         for (auto &t : tails) { if (!seen[t.gene]) { seen[t.gene] = 1; keyed += 5 * (size_t)genes[t.gene].aln.ntax; }
-                                if (t.mode == MODE_EVALUATE && t.bv < 0) loose += 9; }
+                                if (t.mode == MODE_EVALUATE && t.bv < 0) loose += 1; }
         nreq_max = std::min(nreq_max, keyed + loose);
     }
     bool any_pitch = false;
@@ -609,14 +609,24 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     // one request per (gene, kind, tree branch) and launch; never while a plan is being recorded (a replay refreshes
     // each request from ITS branch)
     std::unordered_map<uint64_t, const double *> shared;
+    // requests whose length belongs to no branch of the tree (SPR: joined / halved branches) are shared by VALUE: the
+    // same (gene, kind, length) gives the same matrices: one list of (length bits, matrices) per (gene, kind).
+    std::unordered_map<uint64_t, std::vector<std::pair<uint64_t, const double *>>> shared_val;
     bool req_overflow = false;
     auto add_req = [&](size_t g, double t, int kind, int v, int q) -> const double * {
-        uint64_t key = 0;
-        if (v >= 0 && !record_plan) {
-            const int w = genes[g].tree.nbr[v][q], a = v * 3 + q, b = w * 3 + genes[g].tree.slot(w, v);
-            key = ((uint64_t)g << 34) | ((uint64_t)kind << 32) | (uint64_t)(uint32_t)std::min(a, b);
-            auto it = shared.find(key);
-            if (it != shared.end()) return it->second;
+        uint64_t key = 0, tbits = 0;
+        std::vector<std::pair<uint64_t, const double *>> *bucket = nullptr;
+        if (!record_plan) {
+            if (v >= 0) {
+                const int w = genes[g].tree.nbr[v][q], a = v * 3 + q, b = w * 3 + genes[g].tree.slot(w, v);
+                key = ((uint64_t)g << 34) | ((uint64_t)kind << 32) | (uint64_t)(uint32_t)std::min(a, b);
+                auto it = shared.find(key);
+                if (it != shared.end()) return it->second;
+            } else {
+                std::memcpy(&tbits, &t, 8);
+                bucket = &shared_val[((uint64_t)g << 2) | (uint64_t)kind];          // exact (gene, kind); a few hundred lengths at most
+                for (auto &e : *bucket) if (e.first == tbits) return e.second;
+            }
         }
         if (ireq >= nreq_max) { req_overflow = true; return frags_buf; }
         PmatReq &r = hreq[ireq];
@@ -624,7 +634,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         r.tp = (chain && v >= 0 && genes[g].len_pending[(size_t)v * 3 + q]) ? genes[g].d_len + (size_t)v * 3 + q : nullptr;
         last_src.push_back({(int)g, v, q, kind});
         const double *out = frags_buf + (ireq++) * FRAG_STRIDE;
-        if (v >= 0 && !record_plan) shared.emplace(key, out);
+        if (!record_plan) { if (v >= 0) shared.emplace(key, out); else bucket->push_back({tbits, out}); }
         return out;
     };
     // resolves one side of an op: pointers, kind, scaling counts; `want_table`: newview tip sides look
@@ -696,9 +706,10 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             double *result = t.result_dev ? t.result_dev : d_scalars + 8 * (g * MAXTAIL + t.slot);
             if (t.mode == MODE_EVALUATE) {
                 d.pl = d.pr = add_req(g, t.t0, PM_FRAGS_PI, t.bv, t.bq);
-                d.out = G.d_patlnl[t.slot]; d.out_scl = nullptr;
+                double *pl = t.patlnl_dev ? t.patlnl_dev : G.d_patlnl[t.slot];      // pooled when a gene has more than MAXTAIL tails
+                d.out = pl; d.out_scl = nullptr;
                 ReduceReq &rr = hred[ie++];
-                rr.patlnl = G.d_patlnl[t.slot]; rr.weight = G.d_weight; rr.out = result; rr.mpad = mp; rr.pad = 0;
+                rr.patlnl = pl; rr.weight = G.d_weight; rr.out = result; rr.mpad = mp; rr.pad = 0;
                 algo_bytes += (double)G.aln.npat * (L.bytes + R.bytes + 8);
             } else {
                 d.pl = eig; d.pr = eig + PFRAG;

@@ -115,14 +115,32 @@ static double inc_gamma(double a, double x) {
     }
     return 1 - std::exp(-x + a * std::log(x) - gln) * h;
 }
+// quantile of Gamma(shape a, scale 1): Newton on y = log x inside the bisection bracket (a step that leaves the bracket
+// falls back to its midpoint).  Same root as plain bisection to ~1e-15 relative, in ~6 instead of ~60 evaluations of
+// P(a, x) -- the alpha optimisation calls this three times per gene and Brent step while the device waits.
 static double gamma_quantile(double p, double a) {
     double lo = -1600, hi = std::log(a + 40 * std::sqrt(a) + 400);
-    for (int i = 0; i < 400; ++i) {
-        const double mid = 0.5 * (lo + hi);
-        if (inc_gamma(a, std::exp(mid)) < p) lo = mid; else hi = mid;
-        if (hi - lo < 1e-15 * std::max(1.0, std::fabs(mid))) break;
+    const double gln = std::lgamma(a);
+    // start: small shapes x ~ (p Gamma(a+1))^(1/a); otherwise Wilson-Hilferty with a crude normal quantile
+    double y;
+    if (a < 1.0) y = (std::log(p) + std::lgamma(a + 1)) / a;
+    else {
+        const double z = (p < 0.5 ? -1.0 : 1.0) * std::sqrt(-2.0 * std::log(p < 0.5 ? p : 1 - p)) * 0.6, c = 1.0 / (9.0 * a);
+        const double w = 1.0 - c + z * std::sqrt(c);
+        y = std::log(a) + 3.0 * std::log(w > 0.05 ? w : 0.05);
     }
-    return std::exp(0.5 * (lo + hi));
+    if (!(y > lo && y < hi)) y = 0.5 * (lo + hi);
+    for (int i = 0; i < 200; ++i) {
+        const double x = std::exp(y), F = inc_gamma(a, x) - p;
+        if (F < 0) lo = y; else hi = y;
+        const double dFdy = std::exp(a * y - x - gln);            // density * x
+        double yn = (dFdy > 0 && std::isfinite(dFdy)) ? y - F / dFdy : 0.5 * (lo + hi);
+        if (!(yn > lo && yn < hi)) yn = 0.5 * (lo + hi);
+        const bool done = std::fabs(yn - y) <= 4e-16 * std::max(1.0, std::fabs(y)) || hi - lo < 1e-15 * std::max(1.0, std::fabs(y));
+        y = yn;
+        if (done) break;
+    }
+    return std::exp(y);
 }
 void gamma_rates(double alpha, int K, double *rates) {
     if (K <= 1) { rates[0] = 1.0; return; }

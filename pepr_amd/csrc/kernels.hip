@@ -520,77 +520,82 @@ __device__ __forceinline__ double uni(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
-constexpr int NEWTON_THREADS = 512;           // 8 waves: 7 compute waves (four lanes per pattern -> 112 patterns) + 1 service wave
-constexpr int NEWTON_CWAVES = NEWTON_THREADS / 64 - 1;
-constexpr int NEWTON_SLICE = NEWTON_CWAVES * 16;          // patterns per register-resident slice
+constexpr int NEWTON_THREADS = 512;           // 8 waves, four lanes per pattern -> 128 patterns per workgroup
+constexpr int NEWTON_WAVES = NEWTON_THREADS / 64;
+constexpr int NEWTON_SLICE = NEWTON_WAVES * 16;           // patterns per register-resident slice
 constexpr int NEWTON_ROWS = CLV_ROWS / 4;     // sumtable rows per lane (20 doubles = 40 VGPRs)
 constexpr long NEWTON_SPIN_LIMIT = 4000000L;  // polls (~1 us each) before a slice gives up
 
 struct NewtonShared {
     double exl[NCAT * NS][2];                 // (exp(lambda_i r_k t), lambda_i r_k)
-    double red[3][NEWTON_CWAVES];             // streaming form: the compute waves' sums
-    double fb[3][NEWTON_SLICE];               // register form: per pattern f, f', f'' (the service wave finishes them)
+    double red[3][NEWTON_WAVES];              // streaming form: every wave's sums; register form: [.][0] = service wave A's
+    double fb[3][NEWTON_SLICE];               // register form: per pattern f, f', f'' (the service waves finish them)
+    double xs[2][NEWTON_ROWS][64];            // register form: the two service waves' sumtable rows (LDS instead of VGPRs)
     double bc[4];
 };
 
-// Wave specialisation.  The SERVICE wave (SP) computes the 80 exponentials of every evaluation, combines the compute
-// waves' sums and runs the exchange; the COMPUTE waves hold the slice in registers (REG: lanes 4j..4j+3 own pattern j,
-// each 20 of its 80 sumtable rows, read once from HBM/L2 instead of once per evaluation; quarters combined with two DPP
-// quad swaps) or stream it (slices > 112 patterns: genes of more than 7168 patterns).  The two roles are two
-// instantiations of one body, so the register-hungry f64 exp never meets the 40 live sumtable registers: 8 waves per
-// SIMD = 4 workgroups per CU.  All waves execute the same Newton control flow on the same broadcast sums, so they meet at
-// the same three barriers per evaluation.
-template <bool REG, bool SP>
+// Wave specialisation (ROLE).  Every wave owns 16 patterns (lanes 4j..4j+3 own pattern j, each 20 of its 80 sumtable
+// rows, read once from HBM/L2 instead of once per evaluation; quarters combined with two DPP quad swaps).  Waves 0-5
+// (ROLE 0) keep their rows in 40 VGPRs and do nothing else.  Waves 6 and 7 (ROLE 1, 2: the SERVICE waves) keep theirs in
+// LDS and also do the scalar work of an evaluation: 40 of the 80 f64 exponentials each, then the log and the two divisions
+// of 64 patterns each, wave 7 the cross-workgroup exchange.  The roles are separate instantiations of one body, so the
+// register-hungry exp / log never meet 40 live sumtable registers: the kernel fits 8 waves per SIMD = 4 workgroups per CU
+// = every slice of 128 C3 genes resident at once.  All waves run the same Newton control flow on the same broadcast sums
+// and meet at the same four barriers per evaluation.  Slices > 128 patterns (genes of more than 8192 patterns) stream
+// their rows from L2 in every evaluation (REG = false, a second kernel with a 128-VGPR budget).
+template <bool REG, int ROLE>
 __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, const NewtonReq &r, NewtonShared &sh,
                                             int S, int wg, int p_begin, int p_end) {
+    constexpr bool SVC = ROLE != 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mpad = r.mpad;
     const size_t M = (size_t)mpad;
     u64 *gran = reinterpret_cast<u64 *>(r.sync);       // [parity 2][slice NEWTON_MAX_SPLIT][6] granules, zeroed by the sumtable op
     int nevals = 0;
     bool failed = false;
-    double xr[NEWTON_ROWS]; double rw = 0.0, rscl = 0.0; const int sub = tid & 3;
-    double sw0 = 0.0, ss0 = 0.0, sw1 = 0.0, ss1 = 0.0;   // service wave: weights and scaling counts of its two patterns
-    if (REG && SP) {
-        const int p0 = p_begin + lane, p1 = p_begin + 64 + lane;
-        if (p0 < p_end) { sw0 = r.weight[p0]; ss0 = (double)r.scl[p0]; }
-        if (lane < NEWTON_SLICE - 64 && p1 < p_end) { sw1 = r.weight[p1]; ss1 = (double)r.scl[p1]; }
-    }
-    if (REG && !SP) {
+    double xr[NEWTON_ROWS]; const int sub = tid & 3;
+    double sw = 0.0, ss = 0.0;             // service waves: weight and scaling count of the pattern the lane finishes
+    if (REG) {
         // lanes beyond the slice read its last pattern (a valid address) and carry weight 0: no per-load branches
         const int p = p_begin + (tid >> 2), pc = min(p, p_end - 1);
-        if (p < p_end) { rw = r.weight[p]; rscl = (double)r.scl[p]; }
         const double *col = r.sumtab + (size_t)(sub * NEWTON_ROWS) * M + pc;
+        if (SVC) {
+#pragma unroll 4
+            for (int i = 0; i < NEWTON_ROWS; ++i) sh.xs[ROLE - 1][i][lane] = col[(size_t)i * M];      // read back by the same lane only
+            const int pf = p_begin + 64 * (ROLE - 1) + lane;
+            if (pf < p_end) { sw = r.weight[pf]; ss = (double)r.scl[pf]; }
+        } else {
 #pragma unroll
-        for (int i = 0; i < NEWTON_ROWS; ++i) xr[i] = col[(size_t)i * M];
+            for (int i = 0; i < NEWTON_ROWS; ++i) xr[i] = col[(size_t)i * M];
+        }
     }
-    auto fill_exl = [&](double t) {        // service wave: lane l computes rows l and (l < 16) 64 + l
-#pragma unroll 1                           // one exp chain at a time: interleaved they double the temporaries
-        for (int k = lane; k < NCAT * NS; k += 64) {
+    auto fill_exl = [&](double t) {        // service wave A: rows 0..39, B: rows 40..79
+        if (lane < NCAT * NS / 2) {
+            const int k = (ROLE - 1) * (NCAT * NS / 2) + lane;
             const double lr = md->eval[k % NS] * r.rates[k / NS];
             sh.exl[k][0] = exp(lr * t); sh.exl[k][1] = lr;
         }
     };
 
     auto eval_at = [&](double t, double &L, double &d1, double &d2) {
-        if (SP) fill_exl(t);
+        if (SVC) fill_exl(t);
         __syncthreads();
-        if (!SP) {
-            double acc[3] = {0.0, 0.0, 0.0};
-            if (REG) {
-                double f = 0.0, f1 = 0.0, f2 = 0.0;
+        if (REG) {
+            double f = 0.0, f1 = 0.0, f2 = 0.0;
 #pragma unroll
-                for (int i = 0; i < NEWTON_ROWS; ++i) {
-                    const int row = sub * NEWTON_ROWS + i;
-                    const double xe = xr[i] * sh.exl[row][0], xl = xe * sh.exl[row][1];
-                    f += xe; f1 += xl; f2 += xl * sh.exl[row][1];
-                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // at most 4 LDS pairs in flight
-                }
-                f = quad_sum(f); f1 = quad_sum(f1); f2 = quad_sum(f2);
-                // the log and the two divisions per pattern are left to the service wave (their temporaries would not
-                // fit beside the 40 sumtable registers at 8 waves per SIMD)
-                if (sub == 0) { sh.fb[0][tid >> 2] = f; sh.fb[1][tid >> 2] = f1; sh.fb[2][tid >> 2] = f2; }
-            } else
-            for (int p = p_begin + tid; p < p_end; p += NEWTON_CWAVES * 64) {
+            for (int i = 0; i < NEWTON_ROWS; ++i) {
+                const int row = sub * NEWTON_ROWS + i;
+                const double x = SVC ? sh.xs[ROLE - 1][i][lane] : xr[i];
+                const double xe = x * sh.exl[row][0], xl = xe * sh.exl[row][1];
+                f += xe; f1 += xl; f2 += xl * sh.exl[row][1];
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // at most 4 LDS pairs in flight
+            }
+            f = quad_sum(f); f1 = quad_sum(f1); f2 = quad_sum(f2);
+            // the log and the two divisions per pattern are left to the service waves (their temporaries would not
+            // fit beside the 40 sumtable registers at 8 waves per SIMD)
+            if (sub == 0) { sh.fb[0][tid >> 2] = f; sh.fb[1][tid >> 2] = f1; sh.fb[2][tid >> 2] = f2; }
+        } else {
+            double acc[3] = {0.0, 0.0, 0.0};
+            for (int p = p_begin + tid; p < p_end; p += NEWTON_THREADS) {
                 const double w = r.weight[p];
                 if (w == 0.0) continue;
                 double f = 0.0, f1 = 0.0, f2 = 0.0;
@@ -604,33 +609,32 @@ __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, con
                 acc[1] += w * r1;
                 acc[2] += w * (f2 / f - r1 * r1);
             }
-            if (!REG) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) { const double s = wave_sum(acc[i]); if (lane == 0) sh.red[i][wave] = s; }
-            }
+            for (int i = 0; i < 3; ++i) { const double s = wave_sum(acc[i]); if (lane == 0) sh.red[i][wave] = s; }
         }
         __syncthreads();
-        if (SP) {                            // the workgroup's sums in a fixed order, then the exchange
-            double tot[3];
-            if (REG) {                       // lane l finishes patterns l and 64 + l of the slice
-                double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-#pragma unroll 1
-                for (int h = 0; h < 2; ++h) {
-                    const double w = h ? sw1 : sw0, sc = h ? ss1 : ss0;
-                    if (w != 0.0) {
-                        const int j = 64 * h + lane;
-                        const double f = sh.fb[0][j], r1 = sh.fb[1][j] / f;
-                        a0 += w * (log(f * 0.25) - sc * LOG_2_256); a1 += w * r1; a2 += w * (sh.fb[2][j] / f - r1 * r1);
-                    }
-                }
-                tot[0] = wave_sum(a0); tot[1] = wave_sum(a1); tot[2] = wave_sum(a2);
-                tot[0] = __shfl(tot[0], 0); tot[1] = __shfl(tot[1], 0); tot[2] = __shfl(tot[2], 0);
+        double tot[3] = {0.0, 0.0, 0.0};
+        if (SVC && REG) {                    // lane l of service wave A / B finishes pattern l / 64 + l of the slice
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            if (sw != 0.0) {
+                const int j = 64 * (ROLE - 1) + lane;
+                const double f = sh.fb[0][j], r1 = sh.fb[1][j] / f;
+                a0 = sw * (log(f * 0.25) - ss * LOG_2_256); a1 = sw * r1; a2 = sw * (sh.fb[2][j] / f - r1 * r1);
+            }
+            tot[0] = wave_sum(a0); tot[1] = wave_sum(a1); tot[2] = wave_sum(a2);
+            if (ROLE == 1 && lane == 0) { sh.red[0][0] = tot[0]; sh.red[1][0] = tot[1]; sh.red[2][0] = tot[2]; }
+        }
+        __syncthreads();
+        if (ROLE == 2) {                     // service wave B: the workgroup's sums in a fixed order, then the exchange
+            if (REG) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) tot[i] = sh.red[i][0] + __shfl(tot[i], 0);
             } else {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     double s = sh.red[i][0];
 #pragma unroll
-                    for (int w = 1; w < NEWTON_CWAVES; ++w) s += sh.red[i][w];
+                    for (int w = 1; w < NEWTON_WAVES; ++w) s += sh.red[i][w];
                     tot[i] = s;
                 }
             }
@@ -693,32 +697,34 @@ __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, con
         tn = uni(tn < PML_TMIN ? PML_TMIN : (tn > PML_TMAX ? PML_TMAX : tn));
         if (tiny) { t = tn; break; }
     }
-    if (SP && lane == 0 && wg == 0) {
+    if (ROLE == 2 && lane == 0 && wg == 0) {
         if (failed) { t = r.t0; L = __builtin_nan(""); }      // exchange timeout: reported, the host fails the call
         r.out[0] = t; r.out[1] = L; r.out[2] = d1; r.out[3] = d2;
         if (r.t_dev0) { *r.t_dev0 = t; *r.t_dev1 = t; }
     }
     if (r.patlnl != nullptr) {                  // per-pattern lnL at the returned length (every slice its own patterns)
         __syncthreads();
-        if (SP) fill_exl(t);
+        if (SVC) fill_exl(t);
         __syncthreads();
-        if (!SP) {
-            if (REG) {
-                double f = 0.0;
+        if (REG) {
+            double f = 0.0;
 #pragma unroll
-                for (int i = 0; i < NEWTON_ROWS; ++i) f += xr[i] * sh.exl[sub * NEWTON_ROWS + i][0];
-                f = quad_sum(f);
-                const int p = p_begin + (tid >> 2);
-                if (sub == 0 && p < p_end) r.patlnl[p] = (rw != 0.0) ? log(f * 0.25) - rscl * LOG_2_256 : 0.0;
-            } else {
-                for (int p = p_begin + tid; p < p_end; p += NEWTON_CWAVES * 64) {
-                    double f = 0.0;
-                    if (r.weight[p] != 0.0) {
-                        for (int row = 0; row < CLV_ROWS; ++row) f += r.sumtab[(size_t)row * M + p] * sh.exl[row][0];
-                        f = log(f * 0.25) - r.scl[p] * LOG_2_256;
-                    }
-                    r.patlnl[p] = f;
+            for (int i = 0; i < NEWTON_ROWS; ++i) f += (SVC ? sh.xs[ROLE - 1][i][lane] : xr[i]) * sh.exl[sub * NEWTON_ROWS + i][0];
+            f = quad_sum(f);
+            if (sub == 0) sh.fb[0][tid >> 2] = f;
+            __syncthreads();
+            if (SVC) {                           // the logs, again by the service waves
+                const int j = 64 * (ROLE - 1) + lane, p = p_begin + j;
+                if (p < p_end) r.patlnl[p] = (sw != 0.0) ? log(sh.fb[0][j] * 0.25) - ss * LOG_2_256 : 0.0;
+            }
+        } else {
+            for (int p = p_begin + tid; p < p_end; p += NEWTON_THREADS) {
+                double f = 0.0;
+                if (r.weight[p] != 0.0) {
+                    for (int row = 0; row < CLV_ROWS; ++row) f += r.sumtab[(size_t)row * M + p] * sh.exl[row][0];
+                    f = log(f * 0.25) - r.scl[p] * LOG_2_256;
                 }
+                r.patlnl[p] = f;
             }
         }
     }
@@ -736,13 +742,15 @@ __global__ __launch_bounds__(NEWTON_THREADS, REG ? 8 : 4) void k_newton(const Mo
     // whatever the batch composition
     const int S = min(NEWTON_MAX_SPLIT, (mpad + NEWTON_SLICE - 1) / NEWTON_SLICE);
     if (wg >= S) return;
-    const int slice = ((mpad / 16 + S - 1) / S) * 16;
+    const int slice = ((mpad / 32 + S - 1) / S) * 32;
     if ((slice <= NEWTON_SLICE) != REG) return;
     const int p_begin = wg * slice, p_end = min(mpad, p_begin + slice);
     if (threadIdx.x == 0) sh.bc[3] = 0.0;
     __syncthreads();
-    if ((threadIdx.x >> 6) == NEWTON_CWAVES) newton_body<REG, true>(md, r, sh, S, wg, p_begin, p_end);
-    else newton_body<REG, false>(md, r, sh, S, wg, p_begin, p_end);
+    const int wave = threadIdx.x >> 6;
+    if (wave == NEWTON_WAVES - 1) newton_body<REG, 2>(md, r, sh, S, wg, p_begin, p_end);
+    else if (wave == NEWTON_WAVES - 2) newton_body<REG, 1>(md, r, sh, S, wg, p_begin, p_end);
+    else newton_body<REG, 0>(md, r, sh, S, wg, p_begin, p_end);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -324,22 +324,34 @@ int Batch::nni_round(const std::vector<char> &active, std::vector<double> &lnl, 
 
 // ------------------------------------------------------------------------------------------
 // lazy SPR round (oracle: spr_round / spr_explore / spr_score).  Per gene a small state machine
-// walks (prune node p, neighbour s) in order; every candidate regraft edge is ONE run() unit:
+// walks the prunes (node p, neighbour s) in order; every candidate regraft edge is one unit:
 // [path message of the pruned tree for this depth] + insertion CLV + evaluate across the pendant
 // branch.  Genes advance in lockstep, each on its own tree.
+//
+// Batching.  One run() carries, per gene, the candidates of SEVERAL consecutive prunes (about
+// SPR_UNIT_BUDGET units): all prunes of a batch are scored against the same tree, i.e. under the
+// assumption that none of the earlier ones moves anything -- almost always true after the NNI rounds.
+// The results are then read in prune order: the first prune whose best candidate beats the current
+// likelihood is applied exactly as the sequential procedure applies it (four branch Newtons, keep
+// only if the tree really improved); if the move is kept, the scores of the later prunes of the
+// batch were computed on a tree that no longer exists and are discarded -- scanning resumes behind
+// that prune; if it is rejected the tree is restored and the later scores still stand.  Every
+// decision is the sequential procedure's decision; only the launch granularity changed (round 1:
+// at most four candidates of one prune per launch, 7898 launches for a C4 shard).
 // ------------------------------------------------------------------------------------------
 namespace {
 constexpr double SPR_MIN_GAIN = 0.01;
 constexpr int SPR_MAX_RADIUS = 6;
 constexpr int SPR_INS_SLOT = 7;
-struct PathOp { int depth; Side left; double tl; Side right; double tr; };
+constexpr size_t SPR_UNIT_BUDGET = 96;
+struct PathOp { int depth; Side left; double tl; int lbv, lbq; Side right; double tr; int rbv, rbq; };
 struct Unit { std::vector<PathOp> paths; int g, h, mslot; };   // score candidate edge (g,h) with path slot mslot
+struct Prune { int p, ks, s, x, y; double tx, ty, ts; std::vector<Unit> units; size_t rbase; };
 struct SprState {
-    int p = 0, ks = 0; bool done = false;
-    int s = 0, x = 0, y = 0; double tx = 0, ty = 0, ts = 0;
-    std::vector<Unit> units; size_t ui = 0;
+    int p = 0, ks = 0; bool done = false;        // cursor: next prune to build
+    std::vector<Prune> batch; size_t bi = 0;      // scored prunes waiting to be read, bi = next to read
+    int phase = -1;                               // -1: needs scores; 0: scores in flight; 1..5: applying batch[bi]
     double best = -1e300; int bg = -1, bh = -1;
-    int phase = 0;
     Tree backup;
 };
 void spr_apply(Tree &T, int p, int x, int y, int g, int h) {
@@ -359,15 +371,16 @@ int Batch::spr_round(const std::vector<char> &active, int radius, std::vector<do
     moves.assign(n, 0);
     radius = std::min(radius, SPR_MAX_RADIUS);
     std::vector<SprState> st(n);
+    std::vector<std::vector<double>> scores_of(n);      // per gene: candidate scores of its current batch (Prune::rbase indexes it)
     for (int g = 0; g < n; ++g) { st[g].done = !active[g] || genes[g].aln.ntax < 5; st[g].p = genes[g].aln.ntax; st[g].ks = 0; st[g].phase = -1; }
 
-    // builds the unit list of the prune (p, ks) of gene g (DFS order of the oracle's recursion)
-    auto start_prune = [&](int g) {
-        SprState &S = st[g]; const Tree &T = genes[g].tree; const int nt = T.ntax;
-        S.s = T.nbr[S.p][S.ks];
-        int xy[2]; double lxy[2]; others(T, S.p, S.s, xy, lxy);
-        S.x = xy[0]; S.y = xy[1]; S.tx = lxy[0]; S.ty = lxy[1]; S.ts = T.len[S.p][S.ks];
-        S.units.clear(); S.ui = 0; S.best = -1e300; S.bg = S.bh = -1; S.phase = 0;
+    // the unit list of the prune (p, ks) of gene g (DFS order of the oracle's recursion)
+    auto build_prune = [&](int g, int p, int ks, Prune &P) {
+        const Tree &T = genes[g].tree; const int nt = T.ntax;
+        P.p = p; P.ks = ks; P.s = T.nbr[p][ks];
+        int xy[2]; double lxy[2]; others(T, p, P.s, xy, lxy);
+        P.x = xy[0]; P.y = xy[1]; P.tx = lxy[0]; P.ty = lxy[1]; P.ts = T.len[p][ks];
+        P.units.clear();
         std::vector<PathOp> pending;
         // constraints: regrafting beyond edge (gg,h) turns its split into L(h side) + L(S); if that is
         // incompatible, neither this edge nor anything behind it is a candidate
@@ -376,7 +389,7 @@ int Batch::spr_round(const std::vector<char> &active, int radius, std::vector<do
         if (!cons.empty()) {
             leafs = leaf_sets(T);
             LS.assign((nt + 63) / 64, 0);
-            if (S.s < nt) LS[S.s >> 6] |= 1ULL << (S.s & 63); else LS = leafs[(S.s - nt) * 3 + T.slot(S.s, S.p)];
+            if (P.s < nt) LS[P.s >> 6] |= 1ULL << (P.s & 63); else LS = leafs[(P.s - nt) * 3 + T.slot(P.s, p)];
         }
         auto allowed = [&](int gg, int h) {
             if (cons.empty()) return true;
@@ -388,30 +401,28 @@ int Batch::spr_round(const std::vector<char> &active, int radius, std::vector<do
         std::function<void(int, int, int)> explore = [&](int gg, int h, int depth) {
             if (!allowed(gg, h)) { pending.clear(); return; }
             Unit u; u.paths = pending; pending.clear(); u.g = gg; u.h = h; u.mslot = depth - 1;
-            S.units.push_back(u);
+            P.units.push_back(u);
             if (h < nt || depth >= radius) return;
             int ch[2]; double lc[2]; others(T, h, gg, ch, lc);
             const double tgh = T.len[gg][T.slot(gg, h)];
             for (int i = 0; i < 2; ++i) {
-                pending.push_back({depth, {SIDE_SCRATCH, depth - 1}, tgh, msg(g, ch[1 - i], h), lc[1 - i]});
+                pending.push_back({depth, {SIDE_SCRATCH, depth - 1}, tgh, gg, T.slot(gg, h), msg(g, ch[1 - i], h), lc[1 - i], h, T.slot(h, ch[1 - i])});
                 explore(h, ch[i], depth + 1);
             }
         };
         for (int sidei = 0; sidei < 2; ++sidei) {
-            const int a = sidei == 0 ? S.x : S.y, b = sidei == 0 ? S.y : S.x;
+            const int a = sidei == 0 ? P.x : P.y, b = sidei == 0 ? P.y : P.x;
             if (a < nt) continue;
-            int ch[2]; double lc[2]; others(T, a, S.p, ch, lc);
+            int ch[2]; double lc[2]; others(T, a, p, ch, lc);
             for (int i = 0; i < 2; ++i) {
-                pending.push_back({0, msg(g, b, S.p), S.tx + S.ty, msg(g, ch[1 - i], a), lc[1 - i]});
+                pending.push_back({0, msg(g, b, p), P.tx + P.ty, -1, 0, msg(g, ch[1 - i], a), lc[1 - i], a, T.slot(a, ch[1 - i])});
                 explore(a, ch[i], 1);
             }
         }
     };
-    auto advance_cursor = [&](int g) {
+    auto cursor_next = [&](int g) {
         SprState &S = st[g];
-        S.phase = -1;
         if (++S.ks == 3) { S.ks = 0; ++S.p; }
-        if (S.p >= genes[g].tree.nnodes()) S.done = true;
     };
     auto need_side = [&](int g, const Side &sd, std::vector<PendingOp> &ops) {
         if (sd.kind != SIDE_MSG) return;
@@ -419,54 +430,70 @@ int Batch::spr_round(const std::vector<char> &active, int radius, std::vector<do
         const int v = G.aln.ntax + sd.id / 3, to = G.tree.nbr[v][sd.id % 3];
         need(g, v, to, ops);
     };
+    // which branch the gene optimises in apply phase ph of prune P (oracle order)
+    auto apply_edge = [&](const SprState &S, int ph, int &u, int &v) {
+        const Prune &P = S.batch[S.bi];
+        if (ph == 1) { u = P.p; v = P.s; } else if (ph == 2) { u = P.p; v = S.bg; }
+        else if (ph == 3) { u = P.p; v = S.bh; } else { u = P.x; v = P.y; }
+    };
 
     for (;;) {
         std::vector<PendingOp> ops; std::vector<Tail> tails;
-        std::vector<int> kind(n, -1);       // what each gene submitted: 0 score, 1..4 newton, 5 evaluate
+        std::vector<int> kind(n, -1);       // what each gene submitted: 0 scores, 1..4 newton, 5 evaluate
+        std::vector<size_t> pool_off;       // pooled candidate tails: byte offsets, in tail order
+        size_t nres = 0, pool_bytes = 0;
         bool any = false;
         for (int g = 0; g < n; ++g) {
             SprState &S = st[g];
             if (S.done) continue;
-            // find next prune with at least one candidate
-            while (!S.done && S.phase < 0) {
-                start_prune(g);
-                if (S.units.empty()) advance_cursor(g);
-            }
-            if (S.done) continue;
-            any = true;
             const Tree &T = genes[g].tree;
-            if (S.phase == 0) {
-                // up to MAXTAIL consecutive candidates per run: every message they need is requested
-                // first (regular CLVs), then per candidate [path ops, insertion, evaluate tail]; the
-                // tail is placed right behind its insertion, so one insertion slot serves all
-                const size_t k1 = std::min(S.units.size(), S.ui + (size_t)MAXTAIL);
-                const Side sp = msg(g, S.s, S.p);
-                need_side(g, sp, ops);
-                for (size_t k = S.ui; k < k1; ++k) {
-                    const Unit &u = S.units[k];
-                    for (const PathOp &po : u.paths) { need_side(g, po.left, ops); need_side(g, po.right, ops); }
-                    need_side(g, msg(g, u.h, u.g), ops);
+            if (S.phase < 0) {
+                // next batch: consecutive prunes from the cursor until the unit budget is reached
+                S.batch.clear(); S.bi = 0;
+                size_t units = 0;
+                while (S.p < T.nnodes() && units < SPR_UNIT_BUDGET) {
+                    Prune P; build_prune(g, S.p, S.ks, P);
+                    cursor_next(g);
+                    if (P.units.empty()) continue;
+                    units += P.units.size();
+                    S.batch.push_back(std::move(P));
+                }
+                if (S.batch.empty()) { S.done = true; continue; }
+                S.phase = 0;
+                // every cached message the batch reads, first
+                for (const Prune &P : S.batch) {
+                    need_side(g, msg(g, P.s, P.p), ops);
+                    for (const Unit &u : P.units) {
+                        for (const PathOp &po : u.paths) { need_side(g, po.left, ops); need_side(g, po.right, ops); }
+                        need_side(g, msg(g, u.h, u.g), ops);
+                    }
                 }
                 int count = 0;
                 for (size_t q = 0; q < ops.size(); ++q) if (ops[q].gene == g) ++count;
-                for (size_t k = S.ui; k < k1; ++k) {
-                    const Unit &u = S.units[k];
-                    for (const PathOp &po : u.paths) {
-                        PendingOp o; o.gene = g; o.out_kind = SIDE_SCRATCH; o.out_id = po.depth; o.level = 0;
-                        o.child[0] = po.left; o.t[0] = po.tl; o.child[1] = po.right; o.t[1] = po.tr;
-                        ops.push_back(o); ++count;
+                const size_t pl_bytes = ((size_t)genes[g].aln.mpad * 8 + 255) / 256 * 256;
+                for (Prune &P : S.batch) {
+                    const Side sp = msg(g, P.s, P.p);
+                    P.rbase = nres;
+                    for (const Unit &u : P.units) {
+                        for (const PathOp &po : u.paths) {
+                            PendingOp o; o.gene = g; o.out_kind = SIDE_SCRATCH; o.out_id = po.depth; o.level = 0;
+                            o.child[0] = po.left; o.t[0] = po.tl; o.bv[0] = po.lbv; o.bq[0] = po.lbq;
+                            o.child[1] = po.right; o.t[1] = po.tr; o.bv[1] = po.rbv; o.bq[1] = po.rbq;
+                            ops.push_back(o); ++count;
+                        }
+                        const double tgh = T.len[u.g][T.slot(u.g, u.h)];
+                        PendingOp I; I.gene = g; I.out_kind = SIDE_SCRATCH; I.out_id = SPR_INS_SLOT; I.level = 0;
+                        I.child[0] = {SIDE_SCRATCH, u.mslot}; I.t[0] = 0.5 * tgh; I.child[1] = msg(g, u.h, u.g); I.t[1] = 0.5 * tgh;
+                        ops.push_back(I); ++count;
+                        Tail t{g, sp, {SIDE_SCRATCH, SPR_INS_SLOT}, MODE_EVALUATE, P.ts, 0, 0, count};
+                        t.bv = P.p; t.bq = P.ks;                   // the pendant branch: one matrix set for all its candidates
+                        pool_off.push_back(pool_bytes); pool_bytes += pl_bytes; ++nres;
+                        tails.push_back(t);
                     }
-                    const double tgh = T.len[u.g][T.slot(u.g, u.h)];
-                    PendingOp I; I.gene = g; I.out_kind = SIDE_SCRATCH; I.out_id = SPR_INS_SLOT; I.level = 0;
-                    I.child[0] = {SIDE_SCRATCH, u.mslot}; I.t[0] = 0.5 * tgh; I.child[1] = msg(g, u.h, u.g); I.t[1] = 0.5 * tgh;
-                    ops.push_back(I); ++count;
-                    tails.push_back({g, sp, {SIDE_SCRATCH, SPR_INS_SLOT}, MODE_EVALUATE, S.ts, 0, (int)(k - S.ui), count});
                 }
                 kind[g] = 0;
             } else if (S.phase >= 1 && S.phase <= 4) {
-                int u, v;
-                if (S.phase == 1) { u = S.p; v = S.s; } else if (S.phase == 2) { u = S.p; v = S.bg; }
-                else if (S.phase == 3) { u = S.p; v = S.bh; } else { u = S.x; v = S.y; }
+                int u, v; apply_edge(S, S.phase, u, v);
                 need(g, u, v, ops); need(g, v, u, ops);
                 tails.push_back({g, msg(g, u, v), msg(g, v, u), MODE_SUMTABLE, T.len[u][T.slot(u, v)], 32});
                 kind[g] = S.phase;
@@ -476,41 +503,70 @@ int Batch::spr_round(const std::vector<char> &active, int radius, std::vector<do
                 tails.push_back({g, msg(g, 0, r), msg(g, r, 0), MODE_EVALUATE, T.len[0][0], 0});
                 kind[g] = 5;
             }
+            any = true;
         }
         if (!any) break;
         ++cnt_spr;
+        if (nres) {                             // pooled buffers of the candidate tails (pointers are known only now)
+            if (int rc = ensure_tailpool(pool_bytes)) return rc;
+            if (int rc = ensure_results(nres)) return rc;
+            size_t k = 0;
+            for (auto &t : tails) if (t.mode == MODE_EVALUATE && kind[t.gene] == 0) {
+                t.patlnl_dev = reinterpret_cast<double *>(d_tailpool + pool_off[k]);
+                t.result_dev = d_chain + 4 * k; t.result_host = h_chain + 4 * k; ++k;
+            }
+        }
         if (int rc = run(ops, tails)) return rc;
         for (int g = 0; g < n; ++g) {
             if (kind[g] < 0) continue;
             SprState &S = st[g]; Tree &T = genes[g].tree;
-            const double r0 = res(g)[0];
             if (kind[g] == 0) {
-                const size_t k1 = std::min(S.units.size(), S.ui + (size_t)MAXTAIL);
-                for (size_t k = S.ui; k < k1; ++k) {
-                    const Unit &u = S.units[k];
-                    const double sc = res(g, (int)(k - S.ui))[0];
-                    if (sc > S.best) { S.best = sc; S.bg = u.g; S.bh = u.h; }
+                for (Prune &P : S.batch) {                  // candidate scores leave the mapped result pool now: later runs reuse it
+                    std::vector<double> sc(P.units.size());
+                    for (size_t k = 0; k < P.units.size(); ++k) sc[k] = h_chain[4 * (P.rbase + k)];
+                    P.rbase = scores_of[g].size();
+                    scores_of[g].insert(scores_of[g].end(), sc.begin(), sc.end());
                 }
-                S.ui = k1;
-                if (S.ui < S.units.size()) continue;
-                if (S.bg >= 0 && S.best > lnl[g] + SPR_MIN_GAIN) {
-                    S.backup = T;
-                    spr_apply(T, S.p, S.x, S.y, S.bg, S.bh);
-                    invalidate_all(g);
-                    S.phase = 1;
-                } else advance_cursor(g);
             } else if (kind[g] <= 4) {
-                int u, v;
-                if (kind[g] == 1) { u = S.p; v = S.s; } else if (kind[g] == 2) { u = S.p; v = S.bg; }
-                else if (kind[g] == 3) { u = S.p; v = S.bh; } else { u = S.x; v = S.y; }
-                const double old = T.len[u][T.slot(u, v)];
+                int u, v; apply_edge(S, kind[g], u, v);
+                const double r0 = res(g)[0], old = T.len[u][T.slot(u, v)];
                 if (r0 != old) { T.set_len(u, v, r0); branch_changed(g, u, v); }
                 S.phase = kind[g] + 1;
+                continue;
             } else {
-                if (r0 > lnl[g] + 1e-6) { lnl[g] = r0; moves[g]++; }
-                else { T = S.backup; invalidate_all(g); }
-                advance_cursor(g);
+                const double r0 = res(g)[0];
+                if (r0 > lnl[g] + 1e-6) {
+                    // kept: the tree changed, so the scores of the later prunes of this batch are void -- resume
+                    // right behind this prune, on the new tree
+                    lnl[g] = r0; moves[g]++;
+                    const Prune &P = S.batch[S.bi];
+                    S.p = P.p; S.ks = P.ks; cursor_next(g);
+                    S.batch.clear(); scores_of[g].clear(); S.phase = -1;
+                    if (S.p >= T.nnodes()) S.done = true;
+                    continue;
+                }
+                T = S.backup; invalidate_all(g);         // rejected: same tree as before, later scores still stand
+                ++S.bi;
             }
+            // read the scored prunes in order until one has a candidate that beats the current likelihood
+            S.phase = -1;
+            while (S.bi < S.batch.size()) {
+                const Prune &P = S.batch[S.bi];
+                S.best = -1e300; S.bg = S.bh = -1;
+                for (size_t k = 0; k < P.units.size(); ++k) {
+                    const double sc = scores_of[g][P.rbase + k];
+                    if (sc > S.best) { S.best = sc; S.bg = P.units[k].g; S.bh = P.units[k].h; }
+                }
+                if (S.bg >= 0 && S.best > lnl[g] + SPR_MIN_GAIN) {
+                    S.backup = T;
+                    spr_apply(T, P.p, P.x, P.y, S.bg, S.bh);
+                    invalidate_all(g);
+                    S.phase = 1;
+                    break;
+                }
+                ++S.bi;
+            }
+            if (S.phase < 0) { S.batch.clear(); scores_of[g].clear(); if (S.p >= T.nnodes()) S.done = true; }
         }
     }
     return 0;
