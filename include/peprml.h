@@ -22,6 +22,8 @@
  *                        runs pml_optimize on it, as the reference runs `-f e -t` (:253-272)
  *   pml_bootstrap  <- .../pepr/tree/RAxMLRunner.java:115-132,302-318 (`-f a -x -N`, bootstrapReps > 0)
  *   pml_sh_support <- .../pepr/tree/FastTreeRunner.java:67-70 (`FastTree_WAG -gamma` without -nosupport)
+ *   pml_gamma20    <- .../pepr/tree/FastTreeRunner.java:67-70 (`-gamma`: the "Gamma(20) LogLk ... alpha ... rescaling
+ *                        lengths" step that ends every FastTree_WAG run PEPR makes; its printed tree is what PEPR parses)
  *   pml_concatenate<- .../pepr/alignment/MSAConcatenator.java:78-189 (sorted taxon union, '?' padding)
  *   pml_refine_next<- .../pepr/tree/PhylogeneticTreeRefiner.java:298-359 + AdvancedTree.java:1061-1098
  *   pml_support_tree<- .../pepr/tree/TreeSupportDecorator.java:86-163 addSupportValues(): integer
@@ -196,6 +198,16 @@ int pml_sh_support(pml_ctx *ctx, const pml_alignment *aln, const char *newick, c
                    int nboot, unsigned long long seed, pml_result *out);
 int pml_sh_support_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks,
                          const pml_model *model, int nboot, unsigned long long seed, pml_result *out);
+/* FastTree's `-gamma` likelihood (FastTreeRunner.java:67-70 passes -gamma on every call; SURVEY 8a-11 vi): the given tree's
+ * per-site likelihoods at FastTree's 20 fixed rates 0.05 * 400^(k/19) (five device traversals of four rates), re-weighted
+ * by a discretised Gamma(alpha) with mean `rescale`; alpha and rescale are fitted on that table.  out[i].lnl = Gamma20 lnL,
+ * out[i].alpha = its alpha, out[i].newick = the tree with every length multiplied by rescale_out[i] (what FastTree prints),
+ * out[i].tree_length of that tree.  model->pi_mode selects the frequencies (FastTree_WAG: PML_PI_WAG_FULL); model->alpha
+ * and ncat are not used. */
+int pml_gamma20(pml_ctx *ctx, const pml_alignment *aln, const char *newick, const pml_model *model, pml_result *out,
+                double *rescale_out);
+int pml_gamma20_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks, const pml_model *model,
+                      pml_result *out, double *rescale_out /* n, may be NULL */);
 /* Maximum-parsimony trees (Fitch lengths on the device): randomised stepwise addition (seed 0 =
  * input order) then SPR hill climbing within spr_radius edges (0 = none; RAxML uses 20).  out[i].newick is
  * topology only; out[i].lnl / alpha / tree_length are 0; mp_length[i] (optional) = weighted Fitch length. */

@@ -809,6 +809,92 @@ double po_engine_optimize(po_engine *e, po_tree *t, int opt_alpha, double eps) {
 }
 
 /* ------------------------------------------------------------------------------------------
+ * FastTree's `-gamma` likelihood ("Gamma(20) LogLk ... alpha ... rescaling lengths by ..."), the last step of every
+ * FastTree_WAG run PEPR makes (FastTreeRunner.java:67-70 always passes -gamma).  The program is FastTree 2.1.1 (Price,
+ * Dehal & Arkin 2010), shipped only as a binary; this restates its published procedure (FastTree 2.1 GammaLogLk /
+ * RescaleGammaLogLk) with the discretisation SURVEY.md Appendix B re-derived from the binary's -log output:
+ *   - the tree's per-site likelihoods are taken at 20 FIXED rates r_k = 0.05 * 400^(k/19), one rate at a time;
+ *   - rate k gets the weight P(mult*hi_k) - P(mult*lo_k) of a Gamma(shape alpha, mean 1) distribution, bins cut at the
+ *     arithmetic midpoints of adjacent rates (first from 0, last to infinity);
+ *   - lnL(alpha, mult) = sum_sites ln sum_k w_k L_site,k; alpha and mult are optimised alternately, each by a bounded
+ *     one-dimensional Brent search (here: on log alpha / log mult in [0.01, 10], tolerance 1e-3), for at most 10 rounds,
+ *     stopping when a round gains < 1e-3;  rescale = 1/mult multiplies the printed branch lengths.
+ * PARITY UNPINNED: the survey's probe numbers (alpha 2.930, rescale 1.021, -4623.926 on its 8 x 300 toy) cannot be
+ * re-derived here because that alignment was not kept and the binary may not be run.
+ * ---------------------------------------------------------------------------------------- */
+void po_g20_rates(double *r) { for (int k = 0; k < 20; k++) r[k] = 0.05 * pow(400.0, k / 19.0); }
+void po_g20_weights(double alpha, double mult, double *w) {
+    double r[20], prev = 0.0; po_g20_rates(r);
+    for (int k = 0; k < 20; k++) {
+        double cur = (k == 19) ? 1.0 : po_incgamma(alpha, mult * 0.5 * (r[k] + r[k + 1]) * alpha);
+        w[k] = cur - prev; prev = cur;
+    }
+}
+typedef struct { const double *tab; const int *wt; int npat; } g20_data;
+static double g20_neglnl(const g20_data *d, double la, double lm) {
+    double w[20]; po_g20_weights(exp(la), exp(lm), w);
+    double tot = 0;
+    for (int p = 0; p < d->npat; p++) {
+        const double *t = d->tab + (size_t)p * 20;
+        double mx = t[0]; for (int k = 1; k < 20; k++) if (t[k] > mx) mx = t[k];
+        double s = 0; for (int k = 0; k < 20; k++) s += w[k] * exp(t[k] - mx);
+        tot += d->wt[p] * (mx + log(s));
+    }
+    return -tot;
+}
+/* bounded Brent minimisation (same iteration as eng_opt_alpha / the engine's host-side Brent), absolute tolerance tol */
+static double g20_brent(const g20_data *d, int which, double *la, double *lm, double fx0, double lo, double hi, double tol) {
+    const double gold = 0.3819660112501051;
+    double a = lo, b = hi, x = which ? *lm : *la, w = x, v = x, fx = fx0, fw = fx0, fv = fx0, dd = 0, ee = 0;
+    for (int it = 0; it < 60; it++) {
+        double xm = 0.5 * (a + b), tol1 = tol, tol2 = 2 * tol1, u;
+        if (fabs(x - xm) <= tol2 - 0.5 * (b - a)) break;
+        int golden = 1;
+        if (fabs(ee) > tol1) {
+            double r = (x - w) * (fx - fv), q = (x - v) * (fx - fw), p = (x - v) * q - (x - w) * r;
+            q = 2 * (q - r); if (q > 0) p = -p; q = fabs(q);
+            double etemp = ee; ee = dd;
+            if (!(fabs(p) >= fabs(0.5 * q * etemp) || p <= q * (a - x) || p >= q * (b - x))) {
+                dd = p / q; u = x + dd; if (u - a < tol2 || b - u < tol2) dd = (xm - x >= 0) ? tol1 : -tol1; golden = 0;
+            }
+        }
+        if (golden) { ee = (x >= xm) ? a - x : b - x; dd = gold * ee; }
+        u = (fabs(dd) >= tol1) ? x + dd : x + (dd >= 0 ? tol1 : -tol1);
+        double fu = which ? g20_neglnl(d, *la, u) : g20_neglnl(d, u, *lm);
+        if (fu <= fx) { if (u >= x) a = x; else b = x; v = w; fv = fw; w = x; fw = fx; x = u; fx = fu; }
+        else { if (u < x) a = u; else b = u; if (fu <= fw || w == x) { v = w; fv = fw; w = u; fw = fu; } else if (fu <= fv || v == x || v == w) { v = u; fv = fu; } }
+    }
+    if (which) *lm = x; else *la = x;
+    return fx;
+}
+double po_gamma20(const po_aln *a, const po_model *m, const po_tree *t, double *alpha_out, double *rescale_out, double *table_out) {
+    const int np = a->npat;
+    double rates[20]; po_g20_rates(rates);
+    double *tab = (double *)malloc(sizeof(double) * (size_t)(np > 0 ? np : 1) * 20), *pat = (double *)malloc(sizeof(double) * (size_t)(np > 0 ? np : 1));
+    for (int k = 0; k < 20; k++) {             /* likelihood at rate r_k = likelihood of the tree with every length x r_k at rate 1 */
+        po_tree *tk = po_tree_copy(t);
+        for (int i = 0; i < tk->nnodes; i++) for (int q = 0; q < 3; q++) if (tk->nbr[i][q] >= 0) tk->len[i][q] *= rates[k];
+        po_engine *e = po_engine_create(a, m, 1, 1.0);
+        po_engine_lnl(e, tk, pat);
+        for (int p = 0; p < np; p++) tab[(size_t)p * 20 + k] = pat[p];
+        po_engine_free(e); po_tree_free(tk);
+    }
+    g20_data d = { tab, a->weight, np };
+    double la = 0.0, lm = 0.0, f = g20_neglnl(&d, la, lm);
+    const double LO = log(0.01), HI = log(10.0);
+    for (int round = 0; round < 10; round++) {
+        const double start = f;
+        f = g20_brent(&d, 0, &la, &lm, f, LO, HI, 1e-3);
+        f = g20_brent(&d, 1, &la, &lm, f, LO, HI, 1e-3);
+        if (!(f < start - 1e-3)) break;
+    }
+    if (table_out) memcpy(table_out, tab, sizeof(double) * (size_t)np * 20);
+    free(tab); free(pat);
+    *alpha_out = exp(la); *rescale_out = exp(-lm);
+    return -f;
+}
+
+/* ------------------------------------------------------------------------------------------
  * brute force
  * ---------------------------------------------------------------------------------------- */
 double po_bruteforce_lnl(const po_aln *a, const po_model *m, int K, double alpha, const po_tree *t) {

@@ -106,6 +106,12 @@ po_tree *po_nj_tree(const po_aln *a);
  * returns the number of edges written */
 int po_engine_sh_support(po_engine *e, const po_tree *t, int nboot, unsigned long long seed, double *support);
 
+/* ---- FastTree's `-gamma` step: Gamma20 lnL of a given tree, alpha and length rescale fitted on the per-pattern x rate table
+ * (spec in pml_oracle.c); table_out (optional) = npat x 20 per-pattern ln likelihoods, pattern-major ---- */
+void po_g20_rates(double *rates20);
+void po_g20_weights(double alpha, double mult, double *w20);
+double po_gamma20(const po_aln *a, const po_model *m, const po_tree *t, double *alpha_out, double *rescale_out, double *table_out);
+
 /* ---- parsimony (`raxmlHPC -y` start tree; spec in pml_oracle.c) ---- */
 long long po_parsimony_length(const po_aln *a, const po_tree *t);     /* weighted Fitch length */
 po_tree *po_parsimony_tree(const po_aln *a, unsigned seed, int radius, long long *length_out, int *moves_out);

@@ -63,6 +63,10 @@ def lib():
         L.po_engine_search.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_double]
         L.po_nj_tree.restype = vp
         L.po_nj_tree.argtypes = [vp]
+        L.po_gamma20.restype = C.c_double
+        L.po_gamma20.argtypes = [vp, vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.po_g20_weights.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double)]
+        L.po_g20_rates.argtypes = [C.POINTER(C.c_double)]
         L.po_engine_sh_support.restype = C.c_int
         L.po_engine_sh_support.argtypes = [vp, vp, C.c_int, C.c_ulonglong, C.POINTER(C.c_double)]
         L.po_parsimony_length.restype = C.c_longlong
@@ -215,6 +219,26 @@ class Engine:
             lib().po_engine_free(self.ptr)
         except Exception:
             pass
+
+
+def gamma20(aln, model, tree, table=False):
+    """FastTree's -gamma step: (Gamma20 lnL, alpha, rescale[, npat x 20 per-pattern ln likelihoods])."""
+    a, r = C.c_double(), C.c_double()
+    tab = np.zeros((max(aln.npat, 1), 20)) if table else None
+    v = lib().po_gamma20(aln.ptr, model.ptr, tree.ptr, C.byref(a), C.byref(r), tab.ctypes.data_as(C.POINTER(C.c_double)) if table else None)
+    return (v, a.value, r.value, tab[:aln.npat]) if table else (v, a.value, r.value)
+
+
+def g20_weights(alpha, mult):
+    w = np.zeros(20)
+    lib().po_g20_weights(alpha, mult, w.ctypes.data_as(C.POINTER(C.c_double)))
+    return w
+
+
+def g20_rates():
+    r = np.zeros(20)
+    lib().po_g20_rates(r.ctypes.data_as(C.POINTER(C.c_double)))
+    return r
 
 
 def nj_tree(aln):

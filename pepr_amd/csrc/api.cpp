@@ -425,6 +425,38 @@ int pml_sh_support(pml_ctx *ctx, const pml_alignment *aln, const char *newick, c
     return pml_sh_support_batch(ctx, 1, aln, &newick, model, nboot, seed, out);
 }
 
+int pml_gamma20_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks, const pml_model *model,
+                      pml_result *out, double *rescale_out) {
+    if (!ctx || !alns || !newicks || !out || n <= 0) return PML_EINVAL;
+    for (int i = 0; i < n; ++i) { std::memset(&out[i], 0, sizeof(pml_result)); if (!newicks[i]) return ctx->c.fail(PML_EINVAL, "newick required"); }
+    std::lock_guard<std::mutex> lk(ctx->c.mu);
+    pml_batch *b = nullptr;
+    pml_model m = model ? *model : pml_model{4, 1.0, PML_PI_WAG_FULL};
+    m.ncat = 4;
+    int rc = batch_create_impl(ctx, n, alns, newicks, &m, true, &b);
+    if (rc) return rc;
+    try {
+        std::vector<double> lnl, al, rs;
+        rc = b->b.gamma20(lnl, al, rs);
+        for (int i = 0; i < n && !rc; ++i) {
+            const Gene &G = b->b.genes[i];
+            Tree T = G.tree;
+            for (auto &l : T.len) for (double &x : l) x *= rs[i];
+            out[i].lnl = lnl[i]; out[i].alpha = al[i]; out[i].tree_length = T.length(); out[i].npatterns = G.aln.npat; out[i].nsites = G.aln.nsites;
+            out[i].newick = dup_string(T.newick(G.aln.names, 10));
+            if (!out[i].newick) rc = ctx->c.fail(PML_ENOMEM, "host allocation failed");
+            if (rescale_out) rescale_out[i] = rs[i];
+        }
+    } catch (const std::bad_alloc &) { rc = ctx->c.fail(PML_ENOMEM, "host allocation failed"); }
+    catch (const std::exception &e) { rc = ctx->c.fail(PML_EINVAL, e.what()); }
+    b->b.destroy(); delete b;
+    for (int i = 0; i < n; ++i) out[i].status = rc;
+    return rc;
+}
+int pml_gamma20(pml_ctx *ctx, const pml_alignment *aln, const char *newick, const pml_model *model, pml_result *out, double *rescale_out) {
+    return pml_gamma20_batch(ctx, 1, aln, &newick, model, out, rescale_out);
+}
+
 int pml_refine_next(const char *newick, int cutoff, int ndone, const char *const *done, char **ingroup_out, int *nnodes_out, int **mean_out) {
     if (!newick || !ingroup_out || ndone < 0 || (ndone > 0 && !done)) return PML_EINVAL;
     *ingroup_out = nullptr; if (mean_out) *mean_out = nullptr; if (nnodes_out) *nnodes_out = 0;

@@ -554,7 +554,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     std::stable_sort(ops.begin(), ops.end(), [](const PendingOp &a, const PendingOp &b) { return a.gene < b.gene; });
     const size_t nops = ops.size(), ntail = tails.size();
     size_t neval = 0, nnewton = 0;
-    for (auto &t : tails) { if (t.mode == MODE_EVALUATE) neval++; else nnewton++; }
+    for (auto &t : tails) { if (t.mode == MODE_EVALUATE) neval++; else if (t.mode != MODE_EVALUATE_CAT) nnewton++; }
     // <= 5 requests per side (pitchfork: 3 tables + 2 fragment sets) -- but requests across the same tree branch are
     // shared within the launch (add_req), so a gene never needs more than 5 per taxon plus those of lengths that
     // belong to no branch of the tree (SPR path / insertion operations)
@@ -565,7 +565,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         for (auto &o : ops) { if (!seen[o.gene]) { seen[o.gene] = 1; keyed += 5 * (size_t)genes[o.gene].aln.ntax; }
                               if (o.out_kind != SIDE_MSG) loose += (o.bv[0] < 0) + (o.bv[1] < 0); }      // one fragment set per child whose length is no tree branch
         for (auto &t : tails) { if (!seen[t.gene]) { seen[t.gene] = 1; keyed += 5 * (size_t)genes[t.gene].aln.ntax; }
-                                if (t.mode == MODE_EVALUATE && t.bv < 0) loose += 1; }
+                                if (t.mode >= MODE_EVALUATE && t.bv < 0) loose += 1; }
         nreq_max = std::min(nreq_max, keyed + loose);
     }
     bool any_pitch = false;
@@ -704,7 +704,12 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             d.l = L.s; d.r = R.s; d.l_scl = L.scl; d.r_scl = R.scl;
             d.flags = L.kind | (R.kind << 2); d.mpad = mp; d.mode = t.mode;
             double *result = t.result_dev ? t.result_dev : d_scalars + 8 * (g * MAXTAIL + t.slot);
-            if (t.mode == MODE_EVALUATE) {
+            if (t.mode == MODE_EVALUATE_CAT) {
+                if (!t.patlnl_dev || !t.scl_dev) return ctx->fail(-1, "internal: table slice missing");
+                d.pl = d.pr = add_req(g, t.t0, PM_FRAGS_PI, t.bv, t.bq);
+                d.out = t.patlnl_dev; d.out_scl = t.scl_dev;
+                algo_bytes += (double)G.aln.npat * (L.bytes + R.bytes + 36);
+            } else if (t.mode == MODE_EVALUATE) {
                 d.pl = d.pr = add_req(g, t.t0, PM_FRAGS_PI, t.bv, t.bq);
                 double *pl = t.patlnl_dev ? t.patlnl_dev : G.d_patlnl[t.slot];      // pooled when a gene has more than MAXTAIL tails
                 d.out = pl; d.out_scl = nullptr;
@@ -774,7 +779,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
 
     if (req_overflow) return ctx->fail(-5, "internal: transition-matrix request bound exceeded");
     double newton_bytes = 0;
-    for (auto &t : tails) if (t.mode != MODE_EVALUATE) newton_bytes += (double)genes[t.gene].aln.npat * 640;
+    for (auto &t : tails) if (t.mode < MODE_EVALUATE) newton_bytes += (double)genes[t.gene].aln.npat * 640;
     Deferred L;
     L.base = base; L.bytes = bytes; L.o_req = o_req; L.o_ops = o_ops; L.o_runs = o_runs; L.o_red = o_red; L.o_newt = o_newt;
     L.nreq = ireq; L.nruns = nruns; L.neval = neval; L.nnewton = nnewton; L.max_mpad = max_mpad; L.newton_maxm = newton_maxm;
@@ -799,6 +804,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         // a Newton request whose cross-workgroup exchange timed out reports lnL = NaN (k_newton): that is a device
         // failure, never a result
         for (auto &t : tails) {
+            if (t.mode == MODE_EVALUATE_CAT) continue;
             const double *h = t.result_host ? t.result_host : (t.result_dev ? nullptr : res(t.gene, t.slot));
             if (h && !std::isfinite(t.mode == MODE_EVALUATE ? h[0] : h[1]))
                 return ctx->fail(-5, t.mode == MODE_EVALUATE ? "device returned a non-finite likelihood" : "k_newton: cross-workgroup exchange timed out (non-finite result)");
@@ -1036,6 +1042,86 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
         for (auto &G : genes) std::fill(G.len_pending.begin(), G.len_pending.end(), 0);
     }
     for (int g = 0; g < n; ++g) if (active[g]) genes[g].dirty.swap(next[g]);
+    return 0;
+}
+
+// FastTree's `-gamma` likelihood (FastTreeRunner.java:67-70 always passes it): the tree's per-pattern likelihoods at 20
+// fixed rates, re-weighted by a discretised Gamma(alpha) whose mean is 1/mult; alpha and mult are fitted by alternating
+// one-dimensional Brent searches on log alpha / log mult in [0.01, 10] (tolerance 1e-3, <= 10 rounds, stop when a round
+// gains < 1e-3), the spec of oracle/pml_oracle.c po_gamma20.  Reported: Gamma20 lnL, alpha, rescale = 1/mult (FastTree
+// prints the tree with lengths x rescale).  Device work: five full traversals writing the table, then one tiny k_g20
+// launch per objective evaluation for all genes together.
+int Batch::gamma20(std::vector<double> &lnl20, std::vector<double> &alpha20, std::vector<double> &rescale20) {
+    const int n = (int)genes.size();
+    HIPCHK(hipSetDevice(ctx->device));
+    double rates[G20_RATES]; g20_rates(rates);
+    std::vector<size_t> off(n); size_t bytes = 0;
+    for (int g = 0; g < n; ++g) { off[g] = bytes; bytes += align_up((size_t)genes[g].aln.mpad * (G20_RATES * 8 + (G20_RATES / 4) * 4), 256); }
+    if (int rc = ensure_tailpool(bytes)) return rc;
+    auto table = [&](int g) { return reinterpret_cast<double *>(d_tailpool + off[g]); };
+    auto counts = [&](int g) { return reinterpret_cast<int *>(d_tailpool + off[g] + (size_t)genes[g].aln.mpad * G20_RATES * 8); };
+    for (int j = 0; j < G20_RATES / 4; ++j) {
+        std::vector<PendingOp> ops; std::vector<Tail> tails;
+        for (int g = 0; g < n; ++g) {
+            Gene &G = genes[g];
+            for (int c = 0; c < 4; ++c) G.rates[c] = rates[4 * j + c];
+            ++G.rates_epoch; invalidate_all(g);
+            const int r = G.tree.nbr[0][0];
+            need(g, r, 0, ops);
+            Tail t{g, msg(g, 0, r), msg(g, r, 0), MODE_EVALUATE_CAT, G.tree.len[0][0], 0, 0, -1, 0, 0};
+            t.patlnl_dev = table(g) + (size_t)4 * j * G.aln.mpad; t.scl_dev = counts(g) + (size_t)j * G.aln.mpad;
+            tails.push_back(t);
+        }
+        if (int rc = run(ops, tails)) return rc;
+    }
+    for (int g = 0; g < n; ++g) set_alpha(g, genes[g].alpha);            // back to the gene's Gamma4 rates
+    if (int rc = ensure_results((size_t)n)) return rc;
+    if (int rc = ensure_stage((size_t)n * sizeof(G20Req))) return rc;
+    std::vector<double> la(n, 0.0), lm(n, 0.0), f(n, 0.0);               // log alpha, log mult, -lnL
+    auto objective = [&](const std::vector<char> &act) -> int {
+        G20Req *h = (G20Req *)h_stage; int k = 0;
+        std::vector<int> who;
+        for (int g = 0; g < n; ++g) {
+            if (!act[g]) continue;
+            G20Req &r = h[k++];
+            r.table = table(g); r.cnt = counts(g); r.weight = genes[g].d_weight; r.out = d_chain + 4 * g; r.patlnl = nullptr;
+            r.mpad = genes[g].aln.mpad; r.pad = 0;
+            g20_weights(std::exp(la[g]), std::exp(lm[g]), r.w);
+            who.push_back(g);
+        }
+        if (!k) return 0;
+        HIPCHK(hipMemcpyAsync(d_stage, h_stage, (size_t)k * sizeof(G20Req), hipMemcpyHostToDevice, ctx->stream));
+        launch_g20((const G20Req *)d_stage, k, ctx->stream);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipGetLastError());
+        for (int g : who) { f[g] = -h_chain[4 * g]; if (!std::isfinite(f[g])) return ctx->fail(-5, "device returned a non-finite Gamma20 likelihood"); }
+        return 0;
+    };
+    std::vector<char> all(n, 1), active(n, 1);
+    if (int rc = objective(all)) return rc;
+    const double LO = std::log(0.01), HI = std::log(10.0), TOL = 1e-3;
+    for (int round = 0; round < 10; ++round) {
+        bool any = false; for (char a : active) any |= a;
+        if (!any) break;
+        const std::vector<double> start(f);
+        for (int which = 0; which < 2; ++which) {                          // 0: alpha, 1: mult
+            std::vector<double> &x = which ? lm : la;
+            std::vector<Brent> br(n);
+            std::vector<char> act(active);
+            for (int g = 0; g < n; ++g) if (act[g]) br[g].start(LO, HI, x[g], f[g], TOL);
+            for (;;) {
+                bool moved = false;
+                for (int g = 0; g < n; ++g) { if (!act[g]) continue; if (br[g].propose()) { x[g] = br[g].u; moved = true; } else act[g] = 0; }
+                if (!moved) break;
+                if (int rc = objective(act)) return rc;
+                for (int g = 0; g < n; ++g) if (act[g]) br[g].update(f[g]);
+            }
+            for (int g = 0; g < n; ++g) if (active[g]) { x[g] = br[g].x; f[g] = br[g].fx; }
+        }
+        for (int g = 0; g < n; ++g) if (active[g] && !(f[g] < start[g] - 1e-3)) active[g] = 0;
+    }
+    lnl20.resize(n); alpha20.resize(n); rescale20.resize(n);
+    for (int g = 0; g < n; ++g) { lnl20[g] = -f[g]; alpha20[g] = std::exp(la[g]); rescale20[g] = std::exp(-lm[g]); }
     return 0;
 }
 

@@ -170,6 +170,9 @@ struct Batch {
     int search(bool nni, int spr_radius, bool opt_alpha_flag, double eps, double *lnl);
     // SH-like local supports (FastTree's default output; FastTreeRunner.java:67-70 without -nosupport): per gene one value
     // per internal edge in nni_round's edge order (u ascending, slot ascending, v > u inner), plus the (u, v) pairs
+    // FastTree -gamma: per-pattern likelihoods at the 20 fixed rates (five traversals of four rates), then alpha and the
+    // length rescale fitted on that table (k_g20 evaluates, the host steers two alternating Brent searches per gene)
+    int gamma20(std::vector<double> &lnl20, std::vector<double> &alpha20, std::vector<double> &rescale20);
     int sh_support(int nboot, unsigned long long seed, std::vector<std::vector<double>> &support, std::vector<std::vector<std::pair<int, int>>> &edges_out);
     int *d_site2pat = nullptr; std::vector<size_t> site2pat_off;
     // FastTree -constraints matrix (names, rows of '0' '1' '-'); start trees that violate it are rebuilt
@@ -186,6 +189,7 @@ struct Batch {
                   double *t_dev0 = nullptr, *t_dev1 = nullptr; /* chained pass: d_len entries of the branch */
                   double *patlnl_dev = nullptr;               /* Newton tails: per-pattern lnL at the optimised length */
                   double *sumtab_dev = nullptr;               /* Newton tails: pooled sumtable (80*mpad doubles + mpad ints) instead of the gene's slot buffer */
+                  int *scl_dev = nullptr;                     /* MODE_EVALUATE_CAT: where the scaling counts go (patlnl_dev = the 4 x mpad table slice) */
                   const double *result_host = nullptr;        /* host view of result_dev when it is mapped memory (checked after the sync) */ };
     double *res(int g, int slot = 0) const { return h_scalars + 8 * ((size_t)g * MAXTAIL + slot); }
     Side msg(int g, int node, int toward) const;

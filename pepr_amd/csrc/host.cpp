@@ -142,6 +142,15 @@ static double gamma_quantile(double p, double a) {
     }
     return std::exp(y);
 }
+void g20_rates(double *r) { for (int k = 0; k < 20; ++k) r[k] = 0.05 * std::pow(400.0, k / 19.0); }
+void g20_weights(double alpha, double mult, double *w) {
+    double r[20]; g20_rates(r);
+    double prev = 0.0;
+    for (int k = 0; k < 20; ++k) {
+        const double cur = (k == 19) ? 1.0 : inc_gamma(alpha, mult * 0.5 * (r[k] + r[k + 1]) * alpha);      // shape alpha, rate alpha: mean 1
+        w[k] = cur - prev; prev = cur;
+    }
+}
 void gamma_rates(double alpha, int K, double *rates) {
     if (K <= 1) { rates[0] = 1.0; return; }
     double prev = 0;

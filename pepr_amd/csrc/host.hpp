@@ -83,6 +83,12 @@ void pair_counts(const EncodedAlignment &a, std::vector<int64_t> &cmp, std::vect
 Tree nj_from_counts(int n, const std::vector<int64_t> &cmp, const std::vector<int64_t> &diff, const std::vector<Constraint> *cons = nullptr);
 
 // resumable Brent minimiser on a fixed interval (same control flow as the oracle's eng_opt_alpha)
+// FastTree's Gamma20 discretisation (FastTree 2.1 GammaLogLk): 20 fixed rates 0.05 * 400^(k/19);
+// weight of rate k = P(mult * hi_k; alpha) - P(mult * lo_k; alpha) for a Gamma(shape alpha, mean 1) rate distribution,
+// bin edges at the arithmetic midpoints of adjacent rates (first bin from 0, last to infinity)
+void g20_rates(double *rates20);
+void g20_weights(double alpha, double mult, double *w20);
+
 struct Brent {
     double a, b, x, w, v, fx, fw, fv, d, e, u, tol = 1e-4;
     int iter; bool done;

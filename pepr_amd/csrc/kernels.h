@@ -103,7 +103,24 @@ struct NewtonReq {          // Newton-Raphson on one branch from its sumtable
 constexpr int NEWTON_MAX_SPLIT = 64;    // 128-pattern slices up to 8192 patterns stay register-resident (k_newton)
 constexpr int NEWTON_SYNC_DOUBLES = 2 * NEWTON_MAX_SPLIT * 6;   // two parities x slices x six 8-byte {tag, half a double} granules (three partial sums)
 
-enum { MODE_NEWVIEW = 0, MODE_SUMTABLE = 1, MODE_EVALUATE = 2 };
+// MODE_EVALUATE_CAT: like MODE_EVALUATE but the four categories are NOT averaged: out[c][p] = sum_s L_c[s] (pi P_c . R_c)[s]
+// (plain likelihoods, 4 x mpad doubles) and out_scl[p] = the pattern's scaling count -- the per-site x rate likelihood
+// table of FastTree's Gamma20 re-weighting, four rates per traversal
+enum { MODE_NEWVIEW = 0, MODE_SUMTABLE = 1, MODE_EVALUATE = 2, MODE_EVALUATE_CAT = 3 };
+
+// FastTree -gamma (FastTreeRunner.java:67-70): lnL of one gene under 20 FIXED rates with category weights w[k]:
+//   lnL = sum_p weight[p] * ( ln( sum_k w[k] * table[k][p] * 2^(-256 (cnt[k/4][p] - m_p)) ) - m_p * 256 ln 2 ),  m_p = min_j cnt[j][p]
+constexpr int G20_RATES = 20;
+struct G20Req {
+    const double *table;    // [20][mpad] per-pattern likelihoods, rate k in row k (five MODE_EVALUATE_CAT traversals)
+    const int *cnt;         // [5][mpad] scaling counts of the five traversals
+    const double *weight;   // [mpad] pattern weights
+    double w[G20_RATES];    // category weights
+    double *out;            // lnL
+    double *patlnl;         // optional [mpad]
+    int mpad, pad;
+};
+void launch_g20(const G20Req *reqs, int n, hipStream_t s);
 
 // one gene's patterns copied into a replicate (jackknife concatenation on the device):
 // dst[t][dst_off + p] = rowmap[t] >= 0 ? src[rowmap[t]][p] : gap code, dst_w[dst_off + p] = w[p]

@@ -300,10 +300,17 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
         else if (lk == SK_PITCH) load_pitch(curL, op.l, fLi, cl, cl2, cl3, c, q);
         if (rk == SK_CHERRY) load_cherry(curR, op.r, cr, cr2, c, q);
         else if (rk == SK_PITCH) load_pitch(curR, op.r, fRi, cr, cr2, cr3, c, q);
-        if (mode == MODE_EVALUATE) {
+        if (mode >= MODE_EVALUATE) {
             contract_stream(fR + c * 25 * 16, curR, [&](int st, double y0, double y1) {
                 site0 += curL.v[st].x * y0; site1 += curL.v[st].y * y1;
             });
+            if (mode == MODE_EVALUATE_CAT) {          // this category's likelihood goes out on its own (row c of the table slice)
+                double a0 = site0, a1 = site1;
+                a0 += __shfl_xor(a0, 16); a0 += __shfl_xor(a0, 32);
+                a1 += __shfl_xor(a1, 16); a1 += __shfl_xor(a1, 32);
+                if (q == 0) *reinterpret_cast<GLOBAL_AS dvec2 *>(O + (size_t)c * rowbytes + 8 * p) = (dvec2){a0, a1};
+                site0 = 0.0; site1 = 0.0;
+            }
         } else {
             double aL[5][2];
             contract(aL, fL + c * 25 * 16, curL);
@@ -344,7 +351,7 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
             }
         }
         if (q == 0) { sc.x += n0 ? 1 : 0; sc.y += n1 ? 1 : 0; *reinterpret_cast<GLOBAL_AS ivec2 *>((gptr)op.out_scl + 4 * p) = sc; }
-    } else if (mode == MODE_SUMTABLE) {
+    } else if (mode == MODE_SUMTABLE || mode == MODE_EVALUATE_CAT) {
         if (q == 0) *reinterpret_cast<GLOBAL_AS ivec2 *>((gptr)op.out_scl + 4 * p) = sc;
     } else {
         site0 += __shfl_xor(site0, 16); site0 += __shfl_xor(site0, 32);
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : 3) void k_oplist(
             const double2 *gr = reinterpret_cast<const double2 *>(op.pr);
             double2 *s2 = reinterpret_cast<double2 *>(sP);
             for (int i = tid; i < PFRAG / 2; i += 256) {
-                if (op.mode != MODE_EVALUATE && op.pl) s2[i] = gl[i];
+                if (op.mode < MODE_EVALUATE && op.pl) s2[i] = gl[i];
                 if (op.pr) s2[PFRAG / 2 + i] = gr[i];
             }
             if (any_pitch) {                 // inner fragment sets of pitchfork sides
@@ -807,8 +814,49 @@ __global__ __launch_bounds__(256) void k_sh(const ShReq *__restrict__ reqs) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_g20: FastTree's Gamma20 likelihood of one gene per workgroup from its 20 x mpad table (G20Req).  16 B per rate and
+// pattern read once per evaluation of (alpha, rescale); the table of a C3 gene is 160 KB (L2-resident across the fit's
+// ~50 evaluations): latency-bound, tiny.  Fixed-order reduction.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_g20(const G20Req *__restrict__ reqs) {
+    __shared__ double red[1][4];
+    __shared__ double w[G20_RATES];
+    const G20Req &r = reqs[blockIdx.x];
+    if (threadIdx.x < G20_RATES) w[threadIdx.x] = r.w[threadIdx.x];
+    __syncthreads();
+    const size_t M = (size_t)r.mpad;
+    double acc[1] = {0.0};
+    for (int p = threadIdx.x; p < r.mpad; p += 256) {
+        const double wt = r.weight[p];
+        double l = 0.0;
+        if (wt != 0.0) {
+            int m = r.cnt[p];
+#pragma unroll
+            for (int j = 1; j < G20_RATES / 4; ++j) m = min(m, r.cnt[(size_t)j * M + p]);
+            double sum = 0.0;
+#pragma unroll
+            for (int j = 0; j < G20_RATES / 4; ++j) {
+                const int d = r.cnt[(size_t)j * M + p] - m;            // a traversal rescued more often holds 2^(256 d) x larger numbers
+                const double f = ldexp(1.0, -256 * d);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sum += w[4 * j + c] * r.table[(size_t)(4 * j + c) * M + p] * f;
+            }
+            l = log(sum) - m * LOG_2_256;
+            acc[0] += wt * l;
+        }
+        if (r.patlnl) r.patlnl[p] = l;
+    }
+    block_sum<1, 4>(acc, red);
+    if (threadIdx.x == 0) *r.out = acc[0];
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+void launch_g20(const G20Req *reqs, int n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_g20, dim3((unsigned)n), dim3(256), 0, s, reqs);
+}
 void launch_sh(const ShReq *reqs, int n, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_sh, dim3((unsigned)n), dim3(256), 0, s, reqs);

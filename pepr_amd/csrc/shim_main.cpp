@@ -63,10 +63,10 @@ static pml_alignment view(const Aln &a, std::vector<const char *> &np, std::vect
     return v;
 }
 // re-print branch lengths with `digits` decimals (library returns 20)
-static std::string reformat(const char *nw, int digits, bool raxml_tail) {
+static std::string reformat(const char *nw, int digits, bool raxml_tail, double scale = 1.0) {
     std::string out; const char *p = nw; char buf[64];
     while (*p) {
-        if (*p == ':') { char *e; double v = std::strtod(p + 1, &e); std::snprintf(buf, sizeof buf, ":%.*f", digits, v); out += buf; p = e; }
+        if (*p == ':') { char *e; double v = std::strtod(p + 1, &e) * scale; std::snprintf(buf, sizeof buf, ":%.*f", digits, v); out += buf; p = e; }
         else out += *p++;
     }
     if (raxml_tail && out.size() > 1 && out.back() == ';') { out.pop_back(); out += ":0.0;"; }
@@ -91,7 +91,6 @@ int main(int argc, char **argv) {
         else if (a[0] == '-') return fail(tool, "unknown option " + a);
         else file = argv[i];
     }
-    (void)gamma;
     if (!file) return fail(tool, "usage: FastTree_WAG -gamma -nosupport alignment.faa > tree");
     Aln a; std::string err;
     if (!read_fasta(file, a, err)) return fail(tool, err);
@@ -113,14 +112,24 @@ int main(int argc, char **argv) {
     if (rc) { std::string m = pml_last_error(ctx); pml_destroy(ctx); return fail(tool, m); }
     std::fprintf(stderr, "FastTree_WAG (peprml, MI355X): %d seqs, %d positions, %d patterns\nGamma(4) LogLk = %.3f alpha = %.3f\n",
                  v.ntax, v.nsites, res.npatterns, res.lnl, res.alpha);
+    // -gamma (PEPR always passes it, FastTreeRunner.java:67-70): the likelihood under 20 fixed rates with alpha and a length
+    // rescale fitted on the per-site x rate table; the printed tree carries the rescaled lengths
+    double rescale = 1.0;
+    if (gamma) {
+        pml_result g20;
+        const int rc3 = pml_gamma20(ctx, &v, res.newick, &model, &g20, &rescale);
+        if (rc3) { std::string m = pml_last_error(ctx); pml_result_free(&res); pml_destroy(ctx); return fail(tool, m); }
+        std::fprintf(stderr, "Gamma(20) LogLk = %.3f alpha = %.3f rescaling lengths by %.3f\n", g20.lnl, g20.alpha, rescale);
+        pml_result_free(&g20);
+    }
     if (!nosupport && nboot > 0 && v.ntax > 3) {         // FastTree's default: SH-like local supports (0-1) as inner labels
         pml_model m2 = {4, res.alpha, PML_PI_WAG_FULL};
         pml_result sup;
         const int rc2 = pml_sh_support(ctx, &v, res.newick, &m2, nboot, sh_seed, &sup);
         if (rc2) { std::string m = pml_last_error(ctx); pml_result_free(&res); pml_destroy(ctx); return fail(tool, m); }
-        std::printf("%s\n", reformat(sup.newick, 5, false).c_str());
+        std::printf("%s\n", reformat(sup.newick, 5, false, rescale).c_str());
         pml_result_free(&sup);
-    } else std::printf("%s\n", reformat(res.newick, 5, false).c_str());
+    } else std::printf("%s\n", reformat(res.newick, 5, false, rescale).c_str());
     pml_result_free(&res); pml_destroy(ctx);
     return 0;
 }

@@ -157,6 +157,26 @@ class Context:
         """FastTree's SH-like local supports for given trees: list of dicts, "newick" carries 0-1 labels (3 decimals)."""
         return self._oneshot(self.L.pml_sh_support_batch, genes, newicks, _model(ncat, alpha, pi_mode), (int(nboot), int(seed)))
 
+    def gamma20(self, genes, newicks, pi_mode=PI_WAG_FULL):
+        """FastTree's `-gamma` step on given trees: list of {"lnl" (Gamma20), "alpha", "rescale", "newick" (lengths x rescale)}."""
+        keep = []
+        n = len(genes)
+        alns = (_lib.Alignment * n)(*[_aln_struct(g[0], g[1], keep) for g in genes])
+        nw = (C.c_char_p * n)(*[s.encode() for s in newicks])
+        res = (_lib.Result * n)()
+        rs = (C.c_double * n)()
+        m = _model(4, 1.0, pi_mode)
+        rc = self.L.pml_gamma20_batch(self.ptr, n, alns, nw, C.byref(m), res, rs)
+        out = []
+        if rc == 0:
+            for r, s_ in zip(res, rs):
+                out.append({"lnl": r.lnl, "alpha": r.alpha, "rescale": float(s_), "tree_length": r.tree_length,
+                            "npatterns": r.npatterns, "newick": C.string_at(r.newick).decode()})
+        for r in res:
+            self.L.pml_result_free(C.byref(r))
+        self._check(rc)
+        return out
+
     def bootstrap(self, gene, reps=100, seed=1, spr_radius=5, epsilon=1e-3, alpha=1.0, ncat=4, pi_mode=PI_RAXML_3DP):
         """`raxmlHPC -f a -x seed -N reps`: best ML tree with percent supports + the replicate trees."""
         keep = []

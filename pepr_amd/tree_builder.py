@@ -215,16 +215,21 @@ class FastTreeRunner:
             raise ValueError("nucleotide models are not on the GPU path")
 
     def run(self):
-        """`FastTree_WAG -gamma -nosupport`: NJ start + NNI hill climbing under WAG+Gamma."""
+        """`FastTree_WAG -gamma [-nosupport]` (FastTreeRunner.java:67-86): NJ start + NNI hill climbing under WAG+Gamma, then
+        FastTree's Gamma20 step -- the tree PEPR reads from stdout carries the lengths multiplied by the fitted rescale."""
+        import re
         ctx = self.ctx or default_context()
         try:
             # FastTree_WAG carries the full-precision WAG frequencies, RAxML the 3-decimal ones (SURVEY 8c)
-            r = ctx.search([self.alignment.as_gene()], None, nni=True, spr_radius=0, pi_mode=engine.PI_WAG_FULL,
+            gene = self.alignment.as_gene()
+            r = ctx.search([gene], None, nni=True, spr_radius=0, pi_mode=engine.PI_WAG_FULL,
                            constraints=self._constraint_matrix())[0]
-            self.result, self.lnl = r["newick"], r["lnl"]
+            g20 = ctx.gamma20([gene], [r["newick"]], pi_mode=engine.PI_WAG_FULL)[0]
+            self.lnl, self.gamma20LogLk, self.gamma20Alpha, self.rescale = r["lnl"], g20["lnl"], g20["alpha"], g20["rescale"]
+            self.result = g20["newick"]
             if self.bootstrapReps > 0 and len(self.alignment.getTaxa()) > 3:   # FastTreeRunner.java:67-70: no -nosupport -> SH-like supports
-                s = ctx.sh_support([self.alignment.as_gene()], [r["newick"]], alpha=r["alpha"], pi_mode=engine.PI_WAG_FULL)[0]
-                self.result = s["newick"]
+                s = ctx.sh_support([gene], [r["newick"]], alpha=r["alpha"], pi_mode=engine.PI_WAG_FULL)[0]
+                self.result = re.sub(r":([0-9.eE+-]+)", lambda m: ":%.10f" % (float(m.group(1)) * g20["rescale"]), s["newick"])
         except Exception as e:
             log.error("FastTreeRunner failed: %s", e)
             self.result = None

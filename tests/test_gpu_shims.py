@@ -34,8 +34,18 @@ def test_fasttree_shim(tmp_path, gpu_ctx):
     assert tree.endswith(");") and "LogLk" in r.stderr
     ref = gpu_ctx.search([(names, rows)], None, nni=True, spr_radius=0, pi_mode=engine.PI_WAG_FULL)[0]
     assert engine.rf_distance(tree, ref["newick"]) == 0
-    # 5-decimal lengths as FastTree prints them: rescoring loses < 0.05 lnL
-    again = gpu_ctx.score([(names, rows)], [tree], alpha=ref["alpha"], pi_mode=engine.PI_WAG_FULL)[0]["lnl"]
+    # -gamma: FastTree's closing line and a tree whose lengths carry the fitted rescale
+    import re
+    m = re.search(r"Gamma\(20\) LogLk = (-?[0-9.]+) alpha = ([0-9.]+) rescaling lengths by ([0-9.]+)", r.stderr)
+    assert m, r.stderr
+    g20 = gpu_ctx.gamma20([(names, rows)], [ref["newick"]])[0]
+    assert abs(float(m.group(1)) - g20["lnl"]) < 2e-3 and abs(float(m.group(2)) - g20["alpha"]) < 2e-3 and abs(float(m.group(3)) - g20["rescale"]) < 2e-3
+    tl = sum(float(x) for x in re.findall(r":([0-9.]+)", tree))
+    assert abs(tl - ref["tree_length"] * g20["rescale"]) < 1e-3 * max(1.0, tl)
+    # without -gamma the tree keeps the optimised lengths: 5-decimal lengths as FastTree prints them lose < 0.05 lnL
+    r2 = subprocess.run([FT, "-nosupport", "g.faa"], cwd=tmp_path, capture_output=True, text=True)
+    assert r2.returncode == 0 and "Gamma(20)" not in r2.stderr
+    again = gpu_ctx.score([(names, rows)], [r2.stdout.splitlines()[0]], alpha=ref["alpha"], pi_mode=engine.PI_WAG_FULL)[0]["lnl"]
     assert abs(again - ref["lnl"]) < 0.05
 
 
