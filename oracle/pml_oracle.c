@@ -500,6 +500,8 @@ struct po_engine {
     double ntol;       /* Newton stop: |dt| < ntol */
     unsigned char *dirty, *dirty_next;   /* [node*3+slot]: branch needs re-optimisation (both directions set) */
     long n_newview, n_evaluate, n_deriv;
+    /* topological constraints (FastTree -constraints, FastTreeRunner.java:54-64,243-273): split i = taxa cone[i] | taxa czero[i] */
+    int ncons, cwords; unsigned long long *cone, *czero;
 };
 
 po_engine *po_engine_create(const po_aln *a, const po_model *m, int ncat, double alpha) {
@@ -519,7 +521,7 @@ void po_engine_free(po_engine *e) {
     if (!e) return;
     int nd = (e->nnodes - e->ntax) * 3;
     for (int i = 0; i < nd; i++) { free(e->clv[i]); free(e->scl[i]); }
-    free(e->clv); free(e->scl); free(e->valid); free(e->sumtab); free(e->dirty); free(e->dirty_next); free(e);
+    free(e->clv); free(e->scl); free(e->valid); free(e->sumtab); free(e->dirty); free(e->dirty_next); free(e->cone); free(e->czero); free(e);
 }
 static void eng_invalidate_all(po_engine *e) { memset(e->valid, 0, (size_t)(e->nnodes - e->ntax) * 3); }
 void po_engine_set_alpha(po_engine *e, double alpha) {
@@ -941,8 +943,99 @@ double po_bruteforce_lnl(const po_aln *a, const po_model *m, int K, double alpha
  *   d = -ln max(1 - p - 0.2 p^2, 0.05) over positions where both residues are unambiguous
  *   (3.0 when nothing is comparable); first minimum of the Q criterion wins ties.
  * ---------------------------------------------------------------------------------------- */
-po_tree *po_nj_tree(const po_aln *a) {
+/* ------------------------------------------------------------------------------------------
+ * Topological constraints.  FastTree's -constraints file (PEPR writes it from a constraint tree, one 0/1 column per
+ * node: FastTreeRunner.java:243-273) names splits the result should display; taxa marked '-' or absent from the matrix
+ * are free in that column.  FastTree treats violations as a penalty (soft); the engine and this restatement treat them
+ * as HARD: a column with >= 2 taxa on each side is a split every tree of the search must
+ * be compatible with.  A leaf set X (one side of a tree edge) is compatible with a constraint (A | B) iff X misses A, or
+ * misses B, or contains all of A, or contains all of B.  Shared spec (engine: host.cpp split_compatible / leaf_sets,
+ * search.cpp): NJ joins only clusters whose union is compatible (if no pair is, the unconstrained minimum is taken); an
+ * NNI alternative is a candidate only if the one new split it creates is compatible; an SPR regraft edge (g,h) -- and
+ * everything behind it -- is skipped when leaves(h side) + leaves(pruned subtree) is incompatible; a start tree that
+ * violates a constraint is replaced by the constrained NJ tree.
+ * ---------------------------------------------------------------------------------------- */
+void po_engine_set_constraints(po_engine *e, int ncons, int ntax_c, const char *const *names, const char *const *rows) {
+    free(e->cone); free(e->czero); e->cone = e->czero = NULL; e->ncons = 0;
+    const int n = e->ntax, words = (n + 63) / 64;
+    e->cwords = words;
+    if (ncons <= 0 || ntax_c <= 0) return;
+    int *map = (int *)malloc(sizeof(int) * ntax_c);
+    for (int i = 0; i < ntax_c; i++) { map[i] = -1; for (int t = 0; t < n; t++) if (!strcmp(e->a->names[t], names[i])) { map[i] = t; break; } }
+    e->cone = (unsigned long long *)calloc((size_t)ncons * words, sizeof(unsigned long long));
+    e->czero = (unsigned long long *)calloc((size_t)ncons * words, sizeof(unsigned long long));
+    for (int c = 0; c < ncons; c++) {
+        unsigned long long *one = e->cone + (size_t)e->ncons * words, *zero = e->czero + (size_t)e->ncons * words;
+        memset(one, 0, sizeof(unsigned long long) * words); memset(zero, 0, sizeof(unsigned long long) * words);
+        int n1 = 0, n0 = 0;
+        for (int i = 0; i < ntax_c; i++) {
+            int t = map[i]; if (t < 0) continue;
+            if (rows[i][c] == '1') { one[t >> 6] |= 1ULL << (t & 63); n1++; }
+            else if (rows[i][c] == '0') { zero[t >> 6] |= 1ULL << (t & 63); n0++; }
+        }
+        if (n1 >= 2 && n0 >= 2) e->ncons++;        /* smaller sides are trivially displayed */
+    }
+    free(map);
+}
+static int cons_compatible(const po_engine *e, const unsigned long long *X) {
+    const int words = e->cwords;
+    for (int c = 0; c < e->ncons; c++) {
+        const unsigned long long *one = e->cone + (size_t)c * words, *zero = e->czero + (size_t)c * words;
+        int hit1 = 0, hit0 = 0, all1 = 1, all0 = 1;
+        for (int i = 0; i < words; i++) {
+            if (X[i] & one[i]) hit1 = 1;
+            if (X[i] & zero[i]) hit0 = 1;
+            if ((X[i] & one[i]) != one[i]) all1 = 0;
+            if ((X[i] & zero[i]) != zero[i]) all0 = 0;
+        }
+        if (!(!hit1 || !hit0 || all1 || all0)) return 0;
+    }
+    return 1;
+}
+/* leaves behind node v when the edge towards `from` is cut: L[(v - n)*3 + slot(v, from)] (words each), inner v only */
+static void leafset_rec(const po_tree *t, int v, int from, unsigned long long *L, int words) {
+    const int n = t->ntax;
+    unsigned long long *S = L + ((size_t)(v - n) * 3 + slot_of(t, v, from)) * words;
+    memset(S, 0, sizeof(unsigned long long) * words);
+    for (int k = 0; k < 3; k++) {
+        int w = t->nbr[v][k]; if (w == from) continue;
+        if (w < n) S[w >> 6] |= 1ULL << (w & 63);
+        else { leafset_rec(t, w, v, L, words); const unsigned long long *c = L + ((size_t)(w - n) * 3 + slot_of(t, w, v)) * words; for (int q = 0; q < words; q++) S[q] |= c[q]; }
+    }
+}
+static unsigned long long *tree_leaf_sets(const po_tree *t) {
+    const int n = t->ntax, words = (n + 63) / 64;
+    unsigned long long *L = (unsigned long long *)calloc((size_t)3 * (n - 2) * words, sizeof(unsigned long long));
+    for (int v = n; v < t->nnodes; v++) for (int k = 0; k < 3; k++) leafset_rec(t, v, t->nbr[v][k], L, words);   /* O(n^2): oracle sizes only */
+    return L;
+}
+static void set_of(const po_tree *t, const unsigned long long *L, int words, int node, int toward, unsigned long long *out) {
+    const int n = t->ntax;
+    if (node < n) { memset(out, 0, sizeof(unsigned long long) * words); out[node >> 6] |= 1ULL << (node & 63); }
+    else memcpy(out, L + ((size_t)(node - n) * 3 + slot_of(t, node, toward)) * words, sizeof(unsigned long long) * words);
+}
+static int tree_displays(const po_engine *e, const po_tree *t) {
+    if (e->ncons == 0) return 1;
+    const int n = t->ntax, words = e->cwords;
+    unsigned long long *L = tree_leaf_sets(t);
+    int ok = 1;
+    for (int i = 0; i < 3 * (n - 2) && ok; i++) ok = cons_compatible(e, L + (size_t)i * words);
+    free(L);
+    return ok;
+}
+int po_engine_tree_displays(const po_engine *e, const po_tree *t) { return tree_displays(e, t); }
+
+static po_tree *nj_build(const po_aln *a, const po_engine *ce);
+po_tree *po_nj_tree(const po_aln *a) { return nj_build(a, NULL); }
+po_tree *po_nj_tree_constrained(const po_engine *e) { return nj_build(e->a, e); }
+static po_tree *nj_build(const po_aln *a, const po_engine *ce) {
     int n = a->ntax, N = 2 * n - 2, np = a->npat, i, j, p;
+    const int constrained = ce && ce->ncons > 0, words = (n + 63) / 64;
+    unsigned long long *cl = NULL, *X = NULL;          /* leaf set per node (constrained mode) */
+    if (constrained) {
+        cl = (unsigned long long *)calloc((size_t)N * words, sizeof(unsigned long long)); X = (unsigned long long *)calloc(words, sizeof(unsigned long long));
+        for (i = 0; i < n; i++) cl[(size_t)i * words + (i >> 6)] |= 1ULL << (i & 63);
+    }
     double *D = (double *)calloc((size_t)N * N, sizeof(double));
     for (i = 0; i < n; i++)
         for (j = i + 1; j < n; j++) {
@@ -960,13 +1053,21 @@ po_tree *po_nj_tree(const po_aln *a) {
 #define NJCLAMP(x) ((x) < PO_TMIN ? PO_TMIN : ((x) > PO_TMAX ? PO_TMAX : (x)))
     while (m > 3) {
         for (i = 0; i < m; i++) { double s = 0; for (j = 0; j < m; j++) s += D[(size_t)act[i] * N + act[j]]; r[act[i]] = s; }
-        double best = 1e300; int bi = 0, bj = 1;
+        double best = 1e300; int bi = -1, bj = -1;
+        for (int pass = 0; pass < 2 && bi < 0; pass++)      /* pass 1 (only if no compatible pair exists): unconstrained */
         for (i = 0; i < m; i++) for (j = i + 1; j < m; j++) {
             int x = act[i], y = act[j];
             double q = (m - 2) * D[(size_t)x * N + y] - r[x] - r[y];
-            if (q < best) { best = q; bi = i; bj = j; }
+            if (q < best) {
+                if (constrained && pass == 0) {
+                    for (int w = 0; w < words; w++) X[w] = cl[(size_t)x * words + w] | cl[(size_t)y * words + w];
+                    if (!cons_compatible(ce, X)) continue;
+                }
+                best = q; bi = i; bj = j;
+            }
         }
         int x = act[bi], y = act[bj], u = next++;
+        if (constrained) for (int w = 0; w < words; w++) cl[(size_t)u * words + w] = cl[(size_t)x * words + w] | cl[(size_t)y * words + w];
         double dxy = D[(size_t)x * N + y], lx = 0.5 * dxy + (r[x] - r[y]) / (2.0 * (m - 2));
         t_connect(t, u, x, NJCLAMP(lx)); t_connect(t, u, y, NJCLAMP(dxy - lx));
         for (i = 0; i < m; i++) { int z = act[i]; if (z == x || z == y) continue; double d = 0.5 * (D[(size_t)x * N + z] + D[(size_t)y * N + z] - dxy); D[(size_t)u * N + z] = D[(size_t)z * N + u] = d; }
@@ -977,7 +1078,7 @@ po_tree *po_nj_tree(const po_aln *a) {
         double dxy = D[(size_t)x * N + y], dxz = D[(size_t)x * N + z], dyz = D[(size_t)y * N + z];
         t_connect(t, u, x, NJCLAMP(0.5 * (dxy + dxz - dyz))); t_connect(t, u, y, NJCLAMP(0.5 * (dxy + dyz - dxz))); t_connect(t, u, z, NJCLAMP(0.5 * (dxz + dyz - dxy)));
     }
-    free(D); free(act); free(r);
+    free(D); free(act); free(r); free(cl); free(X);
     return t;
 }
 
@@ -1021,6 +1122,7 @@ static int nni_round(po_engine *e, po_tree *t, double *lnl) {
     nni_cand *cands = (nni_cand *)malloc(sizeof(nni_cand) * (size_t)(n > 3 ? n - 3 : 1));
     double *X = (double *)malloc(sizeof(double) * (size_t)np * K * 20), *Y = (double *)malloc(sizeof(double) * (size_t)np * K * 20);
     int *xs = (int *)malloc(sizeof(int) * np), *ys = (int *)malloc(sizeof(int) * np), *sc = (int *)malloc(sizeof(int) * np);
+    unsigned long long *leafs = e->ncons > 0 ? tree_leaf_sets(t) : NULL;
     for (int u = n; u < t->nnodes; u++) for (int k = 0; k < 3; k++) {
         int v = t->nbr[u][k]; if (v < n || v < u) continue;
         int a[2], c[2]; double la[2], lc[2];
@@ -1040,11 +1142,21 @@ static int nni_round(po_engine *e, po_tree *t, double *lnl) {
             { double corr = 0; for (int p = 0; p < np; p++) corr += e->a->weight[p] * sc[p]; L[alt] -= corr * PO_LOG_2_256; }
         }
         { int *s0 = (int *)malloc(sizeof(int) * np); eng_sumtable(e, t, u, v, s0); double corr = 0; for (int p = 0; p < np; p++) corr += e->a->weight[p] * s0[p]; Lc -= corr * PO_LOG_2_256; free(s0); }
+        if (e->ncons > 0) {            /* an alternative whose new split violates a constraint is not a candidate */
+            const int words = e->cwords;
+            unsigned long long *XA = (unsigned long long *)malloc(sizeof(unsigned long long) * words), *XB = (unsigned long long *)malloc(sizeof(unsigned long long) * words);
+            for (int alt = 1; alt <= 2; alt++) {
+                set_of(t, leafs, words, a[0], u, XA); set_of(t, leafs, words, c[alt - 1], v, XB);
+                for (int w = 0; w < words; w++) XA[w] |= XB[w];
+                if (!cons_compatible(e, XA)) L[alt] = -1e300;
+            }
+            free(XA); free(XB);
+        }
         int best = (L[2] > L[1]) ? 2 : 1;
         double gain = L[best] - Lc;
         if (gain > NNI_MIN_GAIN) { cands[ncand].u = u; cands[ncand].v = v; cands[ncand].alt = best; cands[ncand].gain = gain; cands[ncand].t = T[best]; cands[ncand].order = ncand; ncand++; }
     }
-    free(X); free(Y); free(xs); free(ys); free(sc);
+    free(X); free(Y); free(xs); free(ys); free(sc); free(leafs);
     int applied = 0;
     if (ncand > 0) {
         qsort(cands, ncand, sizeof(nni_cand), cand_cmp);
@@ -1157,6 +1269,7 @@ typedef struct {
     double *pm[SPR_MAX_RADIUS + 1]; int *ps[SPR_MAX_RADIUS + 1];   /* path message per depth */
     double *ins; int *insc;
     double best; int bg, bh;
+    const unsigned long long *leafs; unsigned long long *LS, *tmp;   /* constraints: leaf sets of the tree, of the pruned subtree */
 } spr_ctx;
 
 static double spr_score(spr_ctx *c, side Mgh, int g, int h) {
@@ -1188,6 +1301,11 @@ static double spr_score(spr_ctx *c, side Mgh, int g, int h) {
 /* candidate edge (g,h) reached with path message Mgh (message from g towards h in the pruned tree) */
 static void spr_explore(spr_ctx *c, int g, int h, int depth, side Mgh) {
     const po_tree *t = c->t; po_engine *e = c->e;
+    if (e->ncons > 0) {         /* regrafting beyond (g,h) turns its split into leaves(h side) + leaves(S): incompatible -> neither this edge nor anything behind it */
+        set_of(t, c->leafs, e->cwords, h, g, c->tmp);
+        for (int w = 0; w < e->cwords; w++) c->tmp[w] |= c->LS[w];
+        if (!cons_compatible(e, c->tmp)) return;
+    }
     double sc = spr_score(c, Mgh, g, h);
     if (sc > c->best) { c->best = sc; c->bg = g; c->bh = h; }
     if (h < e->ntax || depth >= c->radius) return;
@@ -1224,6 +1342,8 @@ static int spr_round(po_engine *e, po_tree *t, int radius, double *lnl) {
     spr_ctx c; memset(&c, 0, sizeof c); c.e = e; c.t = t; c.radius = radius;
     for (int d = 0; d <= SPR_MAX_RADIUS; d++) { c.pm[d] = (double *)malloc(sizeof(double) * (size_t)np * K * 20); c.ps[d] = (int *)malloc(sizeof(int) * np); }
     c.ins = (double *)malloc(sizeof(double) * (size_t)np * K * 20); c.insc = (int *)malloc(sizeof(int) * np);
+    unsigned long long *leafs_spr = NULL;
+    c.LS = (unsigned long long *)calloc((size_t)(n + 63) / 64, sizeof(unsigned long long)); c.tmp = (unsigned long long *)calloc((size_t)(n + 63) / 64, sizeof(unsigned long long));
     for (int p = n; p < t->nnodes; p++) for (int ks = 0; ks < 3; ks++) {
         int s = t->nbr[p][ks], xy[2]; double lxy[2];
         others(t, p, s, xy, lxy);
@@ -1231,6 +1351,7 @@ static int spr_round(po_engine *e, po_tree *t, int radius, double *lnl) {
         c.p = p; c.s = s; c.x = x; c.y = y; c.ts = t->len[p][ks];
         c.S = eng_side(e, t, s, p);
         c.best = -1e300; c.bg = c.bh = -1;
+        if (e->ncons > 0) { free(leafs_spr); leafs_spr = tree_leaf_sets(t); c.leafs = leafs_spr; set_of(t, leafs_spr, e->cwords, s, p, c.LS); }
         /* side of x: pruned-tree message from x to each child = f(message y->p over tx+ty, other child) */
         for (int sidei = 0; sidei < 2; sidei++) {
             int a = sidei == 0 ? x : y, b = sidei == 0 ? y : x;      /* explore into a's side; b is across */
@@ -1255,12 +1376,13 @@ static int spr_round(po_engine *e, po_tree *t, int radius, double *lnl) {
         po_tree_free(backup);
     }
     for (int d = 0; d <= SPR_MAX_RADIUS; d++) { free(c.pm[d]); free(c.ps[d]); }
-    free(c.ins); free(c.insc);
+    free(c.ins); free(c.insc); free(c.LS); free(c.tmp); free(leafs_spr);
     return moves;
 }
 
 double po_engine_search(po_engine *e, po_tree **t_inout, int spr_radius, double eps) {
     if (!*t_inout) *t_inout = po_nj_tree(e->a);
+    if (e->ncons > 0 && !tree_displays(e, *t_inout)) { po_tree_free(*t_inout); *t_inout = po_nj_tree_constrained(e); }   /* a start tree that violates the constraints */
     po_tree *t = *t_inout;
     eng_bind(e, t);
     e->ntol = 1e-6;                      /* candidate ranking and local moves: coarse Newton */

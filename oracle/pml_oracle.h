@@ -102,6 +102,12 @@ void po_engine_branch_derivs(po_engine *e, const po_tree *t, int u, int v, doubl
 /* tree search: NJ start (or `start` if non-NULL), NNI (+SPR if spr_radius>0); returns lnL */
 double po_engine_search(po_engine *e, po_tree **t_inout, int spr_radius, double eps);
 po_tree *po_nj_tree(const po_aln *a);
+/* topological constraints (FastTree -constraints matrix: names, rows of '0' '1' '-', one column per split; HARD here -- see
+ * pml_oracle.c): po_engine_search and its NNI / SPR rounds honour them; po_nj_tree_constrained = the start tree used when
+ * the given / NJ start tree violates one */
+void po_engine_set_constraints(po_engine *e, int ncons, int ntax_c, const char *const *names, const char *const *rows);
+po_tree *po_nj_tree_constrained(const po_engine *e);
+int po_engine_tree_displays(const po_engine *e, const po_tree *t);
 /* SH-like local supports (FastTree SHSupport): support[] in internal-edge order (u ascending, slot ascending, v > u inner);
  * returns the number of edges written */
 int po_engine_sh_support(po_engine *e, const po_tree *t, int nboot, unsigned long long seed, double *support);

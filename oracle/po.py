@@ -63,6 +63,10 @@ def lib():
         L.po_engine_search.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_double]
         L.po_nj_tree.restype = vp
         L.po_nj_tree.argtypes = [vp]
+        L.po_engine_set_constraints.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
+        L.po_nj_tree_constrained.restype = vp
+        L.po_nj_tree_constrained.argtypes = [vp]
+        L.po_engine_tree_displays.argtypes = [vp, vp]
         L.po_gamma20.restype = C.c_double
         L.po_gamma20.argtypes = [vp, vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.po_g20_weights.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double)]
@@ -207,6 +211,18 @@ class Engine:
         out = np.zeros(max(self.aln.ntax - 3, 1))
         k = lib().po_engine_sh_support(self.ptr, tree.ptr, nboot, seed, out.ctypes.data_as(C.POINTER(C.c_double)))
         return out[:k]
+
+    def set_constraints(self, names, rows):
+        """FastTree -constraints matrix: one row of '0' '1' '-' per named taxon, one column per split (hard constraints)."""
+        n = len(names)
+        na = (C.c_char_p * n)(*[s.encode() for s in names]); ra = (C.c_char_p * n)(*[s.encode() for s in rows])
+        lib().po_engine_set_constraints(self.ptr, len(rows[0]) if n else 0, n, na, ra)
+
+    def displays(self, tree):
+        return bool(lib().po_engine_tree_displays(self.ptr, tree.ptr))
+
+    def nj_constrained(self):
+        return Tree(aln=self.aln, ptr=lib().po_nj_tree_constrained(self.ptr))
 
     def search(self, start=None, spr_radius=0, eps=1e-3):
         """NJ start (or a copy of `start`), NNI hill climbing; returns (lnL, Tree)."""

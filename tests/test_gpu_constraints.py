@@ -80,3 +80,49 @@ def test_fasttree_shim_constraints(tmp_path, gpu_ctx):
                        cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert _displays(r.stdout.splitlines()[0], clade, names)
+
+
+def _false_clade(names, newick, k, seed):
+    sp = util.splits(newick)
+    rng = np.random.default_rng(seed)
+    while True:
+        clade = frozenset(rng.choice(names, k, replace=False))
+        if clade not in sp and frozenset(names) - clade not in sp:
+            return clade
+
+
+def test_constrained_search_vs_oracle(gpu_ctx, oracle_lib):
+    """The oracle restates the constraint handling (constrained NJ, NNI and SPR candidate filters, replacement of a
+    violating start tree: oracle/pml_oracle.c "Topological constraints"); the constrained search on the device and in the
+    oracle must end in the same tree (RF 0 over resolved branches) with |dlnL| < 1e-3.  Cases: two conflicting (false)
+    clades at once from the NJ start (the constrained NJ tree is used), a false clade with free ('-') and unnamed taxa from
+    a GIVEN start tree that violates it, true constraints from a random start (filters only)."""
+    po = oracle_lib
+    cases = []
+    # (a) two false clades, NJ start
+    names, rows, nw = synth.simulate_alignment(13, 260, 930)
+    c1 = _false_clade(names, nw, 4, 1); c2 = _false_clade([t for t in names if t not in c1], nw, 3, 2)
+    crows = [("1" if t in c1 else "0") + ("1" if t in c2 else "0") for t in names]
+    cases.append((names, rows, None, (list(names), crows), [c1, c2]))
+    # (b) false clade, some taxa free, given (violating) start tree = the generating tree
+    names, rows, nw = synth.simulate_alignment(11, 220, 931)
+    c1 = _false_clade(names, nw, 4, 3)
+    cn = [t for t in names if t != names[-1]]
+    free_t = [t for t in cn if t not in c1][0]
+    crows = [("-" if t == free_t else ("1" if t in c1 else "0")) for t in cn]
+    cases.append((names, rows, nw, (cn, crows), []))
+    # (c) true constraints (every split of the generating tree), random start tree
+    names, rows, nw = synth.simulate_alignment(12, 240, 932)
+    rng = np.random.default_rng(5)
+    start = synth.random_tree(12, rng, [names[j] for j in rng.permutation(12)])[0]
+    cases.append((names, rows, start, engine.constraints_from_tree(nw), []))
+    for names, rows, start, cons, clades in cases:
+        a = po.Alignment(names, rows); e = po.Engine(a, po.Model(0), 4, 1.0)
+        e.set_constraints(cons[0], cons[1])
+        ref_lnl, ref_tree = e.search(po.Tree(start, a) if start else None, 5, 1e-3)
+        assert e.displays(ref_tree)
+        g = gpu_ctx.search([(names, rows)], [start] if start else None, nni=True, spr_radius=5, epsilon=1e-3, constraints=cons)[0]
+        assert util.rf_collapsed(g["newick"], ref_tree.newick(12)) == 0, (g["newick"], ref_tree.newick(6))
+        assert abs(g["lnl"] - ref_lnl) < 1e-3, (g["lnl"], ref_lnl)
+        for c in clades:
+            assert _displays(g["newick"], c, names)
