@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libpeprml.so")
+# PEPRML_LIB: another build of the same library (same-box A/B of kernel variants, tools/bench_ab.sh); never a fallback
+SO_PATH = os.environ.get("PEPRML_LIB") or os.path.join(_HERE, "libpeprml.so")
 
 # every symbol include/peprml.h declares (tests check the library exports all of them)
 SYMBOLS = [

@@ -178,7 +178,7 @@ enum { OP_SCORE, OP_OPTIMIZE, OP_SEARCH };
 static size_t gene_bytes_bound(const pml_alignment &a, bool score_only) {
     const size_t mp = ((size_t)std::max(a.nsites, 1) + 31) / 32 * 32, nt = (size_t)std::max(a.ntax, 3);
     const size_t slots = (score_only ? nt - 2 : 3 * (nt - 2)) + NSCRATCH + MAXTAIL;
-    return slots * CLV_ROWS * mp * 8 + slots * mp * 4 + nt * mp + 64 * mp + (1 << 16);
+    return slots * CLV_ROWS * ((mp + 127) / 128 * 128) * 8 + slots * mp * 4 + nt * mp + 64 * mp + (1 << 16);
 }
 
 static int oneshot_chunk(pml_ctx *ctx, int op, int n, const pml_alignment *alns, const char *const *newicks,

@@ -151,9 +151,9 @@ int Batch::layout(double alpha, bool score_only) {
         off[g] = total;
         total += align_up((size_t)nt * mp, 256);                       // codes
         total += align_up((size_t)mp * 8, 256);                        // weight
-        total += (size_t)(G.slot_cap + NSCRATCH) * CLV_ROWS * mp * 8;  // clv (+ scratch)
+        total += (size_t)(G.slot_cap + NSCRATCH) * clv_doubles(mp) * 8;  // clv (+ scratch), tiled: whole 128-pattern tiles
         total += align_up((size_t)(G.slot_cap + NSCRATCH) * mp * 4, 256);   // scalers
-        total += (size_t)MAXTAIL * CLV_ROWS * mp * 8;                  // sumtables
+        total += (size_t)MAXTAIL * clv_doubles(mp) * 8;                  // sumtables
         total += (size_t)MAXTAIL * align_up((size_t)mp * 4, 256);      // sumtable scalers
         total += (size_t)MAXTAIL * align_up((size_t)mp * 8, 256);      // per-pattern lnL
     }
@@ -178,9 +178,9 @@ int Batch::layout(double alpha, bool score_only) {
         char *p = arena + off[g];
         G.d_codes = (uint8_t *)p; p += align_up((size_t)nt * mp, 256);
         G.d_weight = (double *)p; p += align_up((size_t)mp * 8, 256);
-        G.d_clv = (double *)p; p += (size_t)(G.slot_cap + NSCRATCH) * CLV_ROWS * mp * 8;
+        G.d_clv = (double *)p; p += (size_t)(G.slot_cap + NSCRATCH) * clv_doubles(mp) * 8;
         G.d_scl = (int *)p; p += align_up((size_t)(G.slot_cap + NSCRATCH) * mp * 4, 256);
-        for (int k = 0; k < MAXTAIL; ++k) { G.d_sumtab[k] = (double *)p; p += (size_t)CLV_ROWS * mp * 8; }
+        for (int k = 0; k < MAXTAIL; ++k) { G.d_sumtab[k] = (double *)p; p += clv_doubles(mp) * 8; }
         for (int k = 0; k < MAXTAIL; ++k) { G.d_sumscl[k] = (int *)p; p += align_up((size_t)mp * 4, 256); }
         for (int k = 0; k < MAXTAIL; ++k) { G.d_patlnl[k] = (double *)p; p += align_up((size_t)mp * 8, 256); }
         if (!G.aln.codes.empty()) {
@@ -678,7 +678,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         }
         const int slot = sd.kind == SIDE_MSG ? G.slot_of[sd.id] : G.slot_cap + sd.id;
         if (slot < 0) return -1;
-        R.kind = SK_CLV; R.s.p0 = G.d_clv + (size_t)slot * CLV_ROWS * mp; R.scl = G.d_scl + (size_t)slot * mp; R.bytes = 640;
+        R.kind = SK_CLV; R.s.p0 = G.d_clv + (size_t)slot * clv_doubles(mp); R.scl = G.d_scl + (size_t)slot * mp; R.bytes = 640;
         return 0;
     };
 
@@ -719,7 +719,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             } else {
                 d.pl = eig; d.pr = eig + PFRAG;
                 double *stab = t.sumtab_dev ? t.sumtab_dev : G.d_sumtab[t.slot];
-                int *sscl = t.sumtab_dev ? reinterpret_cast<int *>(t.sumtab_dev + (size_t)CLV_ROWS * mp) : G.d_sumscl[t.slot];
+                int *sscl = t.sumtab_dev ? reinterpret_cast<int *>(t.sumtab_dev + clv_doubles(mp)) : G.d_sumscl[t.slot];
                 d.out = stab; d.out_scl = sscl;
                 d.aux = nsync_buf + (size_t)in * NEWTON_SYNC_DOUBLES;
                 NewtonReq &nr = hnewt[in];
@@ -751,7 +751,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             NvOp &d = hops[nout++];
             std::memset(&d, 0, sizeof d);
             d.mode = MODE_NEWVIEW;
-            d.out = G.d_clv + (size_t)s * CLV_ROWS * mp;
+            d.out = G.d_clv + (size_t)s * clv_doubles(mp);
             d.out_scl = G.d_scl + (size_t)s * mp;
             Resolved S[2];
             if (resolve(g, o.child[0], S[0]) || resolve(g, o.child[1], S[1])) return ctx->fail(-5, "internal: child message has no slot");
@@ -775,6 +775,24 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         }
         if (int rc = flush_tails(true)) return rc;
         run.op_end = (int)nout;
+        // Cache policy of the CLV stores, per gene.  Measured on one box, rotated order (profiles/r02_ab_nontemporal.txt): with
+        // NON-TEMPORAL stores the C3 scoring launch (8 tiles per gene) takes 0.89 ms instead of 0.98 -- written CLVs no longer
+        // push the transition-matrix fragments and tip tables out of L2 / Infinity Cache, which 8 workgroups per gene re-fetch
+        // for every operation -- while the C4 shard (40 tiles per gene: 40 workgroups share each fragment set, and a parent
+        // often finds its child's CLV still in the Infinity Cache) takes 10.15 ms instead of 9.18.  Hence by gene size.
+        // PML_NT_STORE=0 never / 2 always / 3 all but results the next operation reads: A-B arms.
+        static const int nt_policy = std::getenv("PML_NT_STORE") ? std::atoi(std::getenv("PML_NT_STORE")) : 1;
+        const bool small_gene = mp <= 16 * TILE_PAT;
+        for (int i = run.op_begin; i < run.op_end; ++i) {
+            NvOp &d = hops[i];
+            if (d.mode != MODE_NEWVIEW || nt_policy == 0 || (nt_policy == 1 && !small_gene)) continue;
+            bool next_reads = false;
+            if (nt_policy == 3 && i + 1 < run.op_end) {
+                const NvOp &nx = hops[i + 1];
+                next_reads = ((nx.flags & 3) == SK_CLV && nx.l.p0 == d.out) || (((nx.flags >> 2) & 3) == SK_CLV && nx.r.p0 == d.out);
+            }
+            if (!next_reads) d.flags |= OPF_NT_STORE;
+        }
     }
 
     if (req_overflow) return ctx->fail(-5, "internal: transition-matrix request bound exceeded");

@@ -124,7 +124,7 @@ extern "C" int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *gene
                 size_t pats = 0; std::set<std::string> taxa;
                 for (int g : sel) { pats += (size_t)store.items[g].aln.npat; taxa.insert(store.items[g].aln.names.begin(), store.items[g].aln.names.end()); }
                 const size_t mp = (pats + 31) / 32 * 32, nt = std::max<size_t>(taxa.size(), 3), slots = 3 * (nt - 2) + NSCRATCH + MAXTAIL;
-                return slots * CLV_ROWS * mp * 8 + slots * mp * 4 + nt * mp + 64 * mp + (1 << 16);
+                return slots * CLV_ROWS * ((mp + 127) / 128 * 128) * 8 + slots * mp * 4 + nt * mp + 64 * mp + (1 << 16);
             };
             for (int begin = 0; begin < reps_here;) {
                 size_t used = 0; int end = begin;
@@ -204,7 +204,7 @@ extern "C" int pml_bootstrap(pml_ctx *ctx, const pml_alignment *aln, const pml_m
             size_t budget = (size_t)(0.85 * (double)(free_b + ctx->c.arena_cache_bytes));
             if (const char *e = std::getenv("PML_HBM_BUDGET_MB")) budget = (size_t)std::atoll(e) << 20;   // test hook
             const size_t mp = ((size_t)L + 31) / 32 * 32, slots = 3 * ((size_t)n - 2) + NSCRATCH + MAXTAIL;
-            const size_t per_rep = slots * CLV_ROWS * mp * 8 + slots * mp * 4 + (size_t)n * mp + 64 * mp + (1 << 16);
+            const size_t per_rep = slots * CLV_ROWS * ((mp + 127) / 128 * 128) * 8 + slots * mp * 4 + (size_t)n * mp + 64 * mp + (1 << 16);
             const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)reps, budget / per_rep));
             for (int begin = 0; begin < reps; begin += chunk) {
                 const int m = std::min(chunk, reps - begin);

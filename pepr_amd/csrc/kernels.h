@@ -10,6 +10,13 @@ constexpr int NCAT = 4;                // Gamma categories laid out per CLV (nca
 constexpr int CLV_ROWS = NCAT * NS;    // 80 rows of `mpad` doubles: CLV[cat*20+state][pattern]
 constexpr int PFRAG = NCAT * 25 * 16;      // doubles per transition-matrix fragment set (12.8 KB)
 constexpr int PAT_PER_WAVE = 32;       // one MFMA chunk: 2 N-tiles of 16 patterns (16 B / lane)
+// CLVs and sumtables are TILED in HBM: tile k holds patterns [128k, 128k+128) as 80 rows x 128 doubles = 80 KB contiguous,
+// element (row, p) at ((p >> 7) * 80 + row) * 128 + (p & 127).  One k_oplist workgroup / one k_newton slice owns exactly one
+// tile, so every CLV it reads or writes is ONE contiguous 80 KB stream (round 1: 80 separate 1 KB pieces 8 KB apart;
+// profiles/r02_ubench_hbm.txt: contiguous tiles stream 5.9 TB/s for this 2R:1W mix, scattered 1 KB pieces 4.7-5.2).
+constexpr int TILE_PAT = 128;
+constexpr size_t clv_doubles(int mpad) { return (size_t)((mpad + TILE_PAT - 1) / TILE_PAT) * TILE_PAT * (NCAT * NS); }
+constexpr size_t clv_index(int row, int p) { return ((size_t)(p >> 7) * (NCAT * NS) + (size_t)row) * TILE_PAT + (size_t)(p & (TILE_PAT - 1)); }
 constexpr int NCODES = 23;
 // tip table: T[c][code][q][kk] (kk padded to 6) = sum_{j in code} P_c[s = 4 kk + q][j]: the five rows a lane
 // needs (its q, kk = 0..4) are 40 contiguous bytes of a 48-byte, 16-byte-aligned record -> 3 loads instead of 5
@@ -50,6 +57,7 @@ enum { PM_FRAGS = 0, PM_FRAGS_PI = 1, PM_TIPTABLE = 2 };
 //               contraction with the fragment set `f` of branch X-C) and then used like a CLV.
 //               p0,p1,p2 = codes of a,b,c; t0,t1,t2 = their tip tables.
 enum { SK_CLV = 0, SK_TIP = 1, SK_CHERRY = 2, SK_PITCH = 3 };
+constexpr int OPF_NT_STORE = 16;
 struct OpSide {
     const void *p0, *p1, *p2;
     const double *t0, *t1, *t2;
@@ -66,7 +74,7 @@ struct NvOp {
     const double *pl;       // fragment sets (PFRAG doubles); null for a newview SK_TIP side
     const double *pr;
     int mpad;               // padded pattern count (multiple of 32)
-    int flags;              // bits 0-1: left side kind, bits 2-3: right side kind
+    int flags;              // bits 0-1: left side kind, bits 2-3: right side kind, OPF_NT_STORE: store the result non-temporally
     int mode;               // MODE_NEWVIEW / MODE_SUMTABLE / MODE_EVALUATE
     int pad;
     double *aux;            // sumtable ops: the Newton sync block to zero (NEWTON_SYNC_DOUBLES), else null

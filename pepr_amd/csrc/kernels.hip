@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void k_eigfrags(const ModelDev *__restrict__ m
 // ------------------------------------------------------------------------------------------
 typedef double dvec2 __attribute__((ext_vector_type(2)));   // native vectors: loadable from address_space(1)
 typedef int ivec2 __attribute__((ext_vector_type(2)));
+typedef unsigned uvec4 __attribute__((ext_vector_type(4)));
 struct Operand {            // one child's 5 two-pattern B operands of one category
     dvec2 v[5];
 };
@@ -153,10 +154,13 @@ typedef __attribute__((address_space(1))) char *gptr;           // from a descri
 
 // CLV operand: base is wave-uniform (SGPR pair), lane_off the lane's 32-bit byte offset
 // (q*M + p)*8, so the loads compile to the saddr + voffset form without per-row VGPR addresses.
+// CLVs are streamed: every byte is read once per launch, so the loads carry the non-temporal hint (measured, same box,
+// rotated order: C3 scoring launch 0.93-1.00 ms plain, 0.92-0.98 nt loads, 0.85-0.86 nt loads + nt stores; C4 shard 10.1 /
+// 9.3 / 9.9 ms -- profiles/r02_ab_nontemporal.txt).
 __device__ __forceinline__ void load_clv(Operand &o, gcptr base, unsigned lane_off, size_t rowbytes, int c) {
 #pragma unroll
     for (int kk = 0; kk < 5; ++kk)
-        o.v[kk] = *reinterpret_cast<const GLOBAL_AS dvec2 *>(base + (size_t)(c * NS + kk * 4) * rowbytes + lane_off);
+        o.v[kk] = __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS dvec2 *>(base + (size_t)(c * NS + kk * 4) * rowbytes + lane_off));
 }
 // tip operand: 0/1 indicator rows from the LDS table T[code][state] (same for every category)
 __device__ __forceinline__ void load_tip(Operand &o, const unsigned char *__restrict__ T, unsigned codes, int q) {
@@ -261,14 +265,18 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
     // `op` refers to the descriptor in global memory (wave-uniform): fields are fetched by scalar loads
     // where they are used instead of being held in ~34 SGPRs for the whole op
     const int q = lane >> 4;
-    const size_t rowbytes = (size_t)op.mpad * 8;
-    const unsigned lane_off = (unsigned)((size_t)q * rowbytes) + (unsigned)p * 8u;
+    // tiled CLV layout (kernels.h): the chunk's tile starts (p >> 7) * 80 KB into the CLV, rows are 1 KB apart
+    constexpr size_t rowbytes = (size_t)TILE_PAT * 8;
+    const size_t tabrow = (size_t)op.mpad * 8;                 // row pitch of the per-category likelihood table (MODE_EVALUATE_CAT)
+    const unsigned lane_off = (unsigned)(p >> 7) * (unsigned)(CLV_ROWS * rowbytes) + (unsigned)((size_t)q * rowbytes) + (unsigned)(p & (TILE_PAT - 1)) * 8u;
     const int lk = op.flags & 3, rk = (op.flags >> 2) & 3;
+    const bool nt_store = (op.flags & OPF_NT_STORE) != 0;      // wave-uniform: the result is not read again soon (host's call)
     const int mode = op.mode;
     // (a plain tip side goes through the MFMA with its 0/1 indicator operand: the matrix pipe has slack and
     // table gathers for it measured slower)
     gcptr Lp = (gcptr)op.l.p0, Rp = (gcptr)op.r.p0;
     gptr O = (gptr)op.out;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)op.out, 0, 0x7FFFFFFF, 0x00020000);   // raw buffer over the output CLV
     // lane's A-fragment element: 4*k + i with k = q, i = lane&3
     const double *fL = sP + (q * 4 + (lane & 3));
     const double *fR = fL + PFRAG;
@@ -308,7 +316,7 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
                 double a0 = site0, a1 = site1;
                 a0 += __shfl_xor(a0, 16); a0 += __shfl_xor(a0, 32);
                 a1 += __shfl_xor(a1, 16); a1 += __shfl_xor(a1, 32);
-                if (q == 0) *reinterpret_cast<GLOBAL_AS dvec2 *>(O + (size_t)c * rowbytes + 8 * p) = (dvec2){a0, a1};
+                if (q == 0) *reinterpret_cast<GLOBAL_AS dvec2 *>(O + (size_t)c * tabrow + 8 * p) = (dvec2){a0, a1};
                 site0 = 0.0; site1 = 0.0;
             }
         } else {
@@ -317,7 +325,13 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
             contract_stream(fR + c * 25 * 16, curR, [&](int st, double y0, double y1) {
                 const double o0 = aL[st][0] * y0, o1 = aL[st][1] * y1;
                 mx0 = fmax(mx0, o0); mx1 = fmax(mx1, o1);
-                *reinterpret_cast<GLOBAL_AS dvec2 *>(O + (size_t)(c * NS + st * 4) * rowbytes + lane_off) = (dvec2){o0, o1};
+                // buffer stores: the cache policy is an immediate of the instruction, so the two policies are two instructions
+                // under a wave-uniform branch (an if/else of a plain and a __builtin_nontemporal_store is merged by hipcc
+                // into ONE plain store)
+                const uvec4 bits = __builtin_bit_cast(uvec4, ((dvec2){o0, o1}));
+                const int soff = (c * NS + st * 4) * (int)rowbytes;
+                if (nt_store) __builtin_amdgcn_raw_buffer_store_b128(bits, orsrc, lane_off, soff, 2);      // aux 2 = nt
+                else __builtin_amdgcn_raw_buffer_store_b128(bits, orsrc, lane_off, soff, 0);
             });
         }
         if (c + 1 < NCAT) {
@@ -555,7 +569,6 @@ __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, con
                                             int S, int wg, int p_begin, int p_end) {
     constexpr bool SVC = ROLE != 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mpad = r.mpad;
-    const size_t M = (size_t)mpad;
     u64 *gran = reinterpret_cast<u64 *>(r.sync);       // [parity 2][slice NEWTON_MAX_SPLIT][6] granules, zeroed by the sumtable op
     int nevals = 0;
     bool failed = false;
@@ -564,15 +577,15 @@ __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, con
     if (REG) {
         // lanes beyond the slice read its last pattern (a valid address) and carry weight 0: no per-load branches
         const int p = p_begin + (tid >> 2), pc = min(p, p_end - 1);
-        const double *col = r.sumtab + (size_t)(sub * NEWTON_ROWS) * M + pc;
+        const double *col = r.sumtab + clv_index(sub * NEWTON_ROWS, pc);          // tiled sumtable: rows of a tile are 128 doubles apart
         if (SVC) {
 #pragma unroll 4
-            for (int i = 0; i < NEWTON_ROWS; ++i) sh.xs[ROLE - 1][i][lane] = col[(size_t)i * M];      // read back by the same lane only
+            for (int i = 0; i < NEWTON_ROWS; ++i) sh.xs[ROLE - 1][i][lane] = col[(size_t)i * TILE_PAT];      // read back by the same lane only
             const int pf = p_begin + 64 * (ROLE - 1) + lane;
             if (pf < p_end) { sw = r.weight[pf]; ss = (double)r.scl[pf]; }
         } else {
 #pragma unroll
-            for (int i = 0; i < NEWTON_ROWS; ++i) xr[i] = col[(size_t)i * M];
+            for (int i = 0; i < NEWTON_ROWS; ++i) xr[i] = col[(size_t)i * TILE_PAT];
         }
     }
     auto fill_exl = [&](double t) {        // service wave A: rows 0..39, B: rows 40..79
@@ -608,7 +621,7 @@ __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, con
                 double f = 0.0, f1 = 0.0, f2 = 0.0;
 #pragma unroll 8
                 for (int row = 0; row < CLV_ROWS; ++row) {
-                    const double xe = r.sumtab[(size_t)row * M + p] * sh.exl[row][0], xl = xe * sh.exl[row][1];
+                    const double xe = r.sumtab[clv_index(row, p)] * sh.exl[row][0], xl = xe * sh.exl[row][1];
                     f += xe; f1 += xl; f2 += xl * sh.exl[row][1];
                 }
                 const double r1 = f1 / f;
@@ -728,7 +741,7 @@ __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, con
             for (int p = p_begin + tid; p < p_end; p += NEWTON_THREADS) {
                 double f = 0.0;
                 if (r.weight[p] != 0.0) {
-                    for (int row = 0; row < CLV_ROWS; ++row) f += r.sumtab[(size_t)row * M + p] * sh.exl[row][0];
+                    for (int row = 0; row < CLV_ROWS; ++row) f += r.sumtab[clv_index(row, p)] * sh.exl[row][0];
                     f = log(f * 0.25) - r.scl[p] * LOG_2_256;
                 }
                 r.patlnl[p] = f;
@@ -749,7 +762,8 @@ __global__ __launch_bounds__(NEWTON_THREADS, REG ? 8 : 4) void k_newton(const Mo
     // whatever the batch composition
     const int S = min(NEWTON_MAX_SPLIT, (mpad + NEWTON_SLICE - 1) / NEWTON_SLICE);
     if (wg >= S) return;
-    const int slice = ((mpad / 32 + S - 1) / S) * 32;
+    // register form: a slice IS a tile of the sumtable (80 KB contiguous); beyond 64 tiles the slices grow and stream
+    const int slice = (mpad <= NEWTON_SLICE * NEWTON_MAX_SPLIT) ? NEWTON_SLICE : ((mpad / 32 + S - 1) / S) * 32;
     if ((slice <= NEWTON_SLICE) != REG) return;
     const int p_begin = wg * slice, p_end = min(mpad, p_begin + slice);
     if (threadIdx.x == 0) sh.bc[3] = 0.0;

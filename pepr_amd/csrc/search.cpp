@@ -180,7 +180,7 @@ int Batch::nni_round(const std::vector<char> &active, std::vector<double> &lnl, 
     size_t per_edge = 0, need_all = 0, nres_all = 0;
     for (int g = 0; g < n; ++g) {
         if (edges[g].empty()) continue;
-        tb[g] = ((size_t)CLV_ROWS * genes[g].aln.mpad * 8 + (size_t)genes[g].aln.mpad * 4 + 255) / 256 * 256;
+        tb[g] = (clv_doubles(genes[g].aln.mpad) * 8 + (size_t)genes[g].aln.mpad * 4 + 255) / 256 * 256;
         per_edge += 3 * tb[g]; need_all += 3 * tb[g] * edges[g].size(); nres_all += 3 * edges[g].size();
     }
     size_t nedge_max = maxsteps / 3, chunk = nedge_max;
