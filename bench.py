@@ -204,6 +204,8 @@ def main():
     chunks = [list(c) for c in np.array_split(np.arange(len(genes)), nchunks)]
     dt, npat, lnl_all = 0.0, 0, []
     stats = None
+    CLOCK_WARMUP_S = float(os.environ.get("BENCH_CLOCK_WARMUP_S", "1.5"))
+    clock_warmup_steps = 0
     for ci, idx in enumerate(chunks):
         sub = [genes[i] for i in idx]
         batch = engine.Batch(ctx, [(g[0], g[1]) for g in sub], [g[2] for g in sub], alpha=alpha) if sub else None
@@ -218,6 +220,12 @@ def main():
 
         for _ in range(args.warmup):
             lnl = step()
+        # a fresh box needs a second or so of load before the chip and the host hold their clocks (the first processes after
+        # box start measured 1.07 s for the search that later takes 0.83 s, profiles/r02_ab_search_warmup.txt): the same
+        # untimed step, repeated until CLOCK_WARMUP_S have passed
+        t_w = time.perf_counter()
+        while ci == 0 and time.perf_counter() - t_w < CLOCK_WARMUP_S:
+            lnl = step(); clock_warmup_steps += 1
         if ci == 0:
             ctx.kernel_stats(reset=True)
         if world > 1:
@@ -273,8 +281,10 @@ def main():
         # of a long-lived context, which keeps the arena; both are whole inferences and both are reported
         cold, _, _, sb = infer()
         sb.close()
+        warm1, _, _, sb = infer()              # second call: the context keeps its arena, clocks are up
+        sb.close()
         sctx.kernel_stats(reset=True)
-        sdt, tc, slnl, sb = infer()
+        sdt, tc, slnl, sb = infer()            # third call = the reported steady state
         sst = sctx.kernel_stats()
         rf = [engine.rf_distance(genes[i][2], sb.newick(i)) for i in range(len(genes))]
         sb.close()
@@ -301,7 +311,7 @@ def main():
             t = torch.tensor([sdt, cold], dtype=torch.float64, device=pd._device())
             dist.all_reduce(t, op=dist.ReduceOp.MAX); sdt, cold = float(t[0]), float(t[1])
         search = {"gene_trees_per_sec": total / sdt, "seconds": sdt, "setup_seconds_rank0": tc,
-                  "cold_first_call_seconds": cold, "cold_gene_trees_per_sec": total / cold, "genes": total,
+                  "cold_first_call_seconds": cold, "cold_gene_trees_per_sec": total / cold, "second_call_seconds_rank0": warm1, "genes": total,
                   "algorithm": "NJ start + WAG+G4 model optimisation + NNI hill climbing (eps 1e-3); timed from host char rows to Newick",
                   "rf_to_generating_tree_mean_rank0": float(np.mean(rf)), "finite": bool(np.all(np.isfinite(slnl))),
                   # no closed form for a search -> measured call counts x the per-pattern byte figures / time
@@ -325,7 +335,7 @@ def main():
         out = {
             "metric": "M site-lnL/sec (WAG+G4 full-tree likelihood evaluations x alignment patterns); the gene-trees/sec half of BASELINE.json's metric is search.gene_trees_per_sec",
             "value": tot_pat * args.steps / dt / 1e6, "unit": "M site-lnL/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_warmup_steps": clock_warmup_steps,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %s x %d taxa x %d AA sites, WAG+G4 (RAxML PROTGAMMAWAG conventions), seeds 1..G" % (
