@@ -229,6 +229,12 @@ int pml_concatenate(int ngenes, const pml_alignment *genes, int nsel, const int 
  * coalesced into device batches; this reports how many batches ran and how many single calls they carried. */
 int pml_coalescing_stats(pml_ctx *ctx, long long *batches, long long *requests);
 
+/* Every computing entry point runs its host-side arithmetic under the DEFAULT floating-point control state (round to
+ * nearest, no flush-to-zero / denormals-are-zero) whatever the calling thread -- a JVM worker, a Python thread -- came in
+ * with, and restores the caller's state on return: results do not depend on the caller's MXCSR.  Diagnostic: the distinct
+ * control states callers entered with (returns their number; values[] receives up to cap of them). */
+int pml_debug_fpenv(unsigned *values, int cap);
+
 /* profiling: HIP-event time of device kernels since the last reset (cfg.profile = 1) */
 enum { PML_K_PMAT = 0, PML_K_NEWVIEW = 1, PML_K_EVALUATE = 2, PML_K_SUMTABLE = 3, PML_K_NEWTON = 4,
        PML_K_REDUCE = 5,

@@ -18,7 +18,7 @@ SYMBOLS = [
     "pml_batch_create", "pml_batch_destroy", "pml_batch_size", "pml_batch_npatterns",
     "pml_batch_score", "pml_batch_site_lnl", "pml_batch_set_alpha", "pml_batch_optimize",
     "pml_batch_search", "pml_batch_newick", "pml_batch_root_derivs", "pml_free",
-    "pml_rf_distance", "pml_support_tree", "pml_jackknife", "pml_concatenate", "pml_parsimony", "pml_parsimony_batch", "pml_refine_next", "pml_bootstrap", "pml_coalescing_stats", "pml_sh_support", "pml_sh_support_batch", "pml_gamma20", "pml_gamma20_batch", "pml_kernel_stats", "pml_kernel_stats_reset",
+    "pml_rf_distance", "pml_support_tree", "pml_jackknife", "pml_concatenate", "pml_parsimony", "pml_parsimony_batch", "pml_refine_next", "pml_bootstrap", "pml_coalescing_stats", "pml_sh_support", "pml_sh_support_batch", "pml_gamma20", "pml_gamma20_batch", "pml_debug_fpenv", "pml_kernel_stats", "pml_kernel_stats_reset",
 ]
 
 
@@ -114,6 +114,7 @@ def load():
     L.pml_sh_support_batch.argtypes = [vp, C.c_int, ap, cpp, mp, C.c_int, C.c_ulonglong, rp]
     L.pml_gamma20.argtypes = [vp, ap, C.c_char_p, mp, rp, dp]
     L.pml_gamma20_batch.argtypes = [vp, C.c_int, ap, cpp, mp, rp, dp]
+    L.pml_debug_fpenv.argtypes = [C.POINTER(C.c_uint), C.c_int]
     L.pml_concatenate.argtypes = [C.c_int, ap, C.c_int, ip, C.POINTER(vp)]
     L.pml_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_longlong), dp, dp]
     L.pml_kernel_stats_reset.argtypes = [vp]

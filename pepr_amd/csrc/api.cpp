@@ -12,9 +12,23 @@ using namespace pml;
 
 static thread_local std::string g_err;
 
+static std::mutex g_fp_mu; static unsigned g_fp_seen[16]; static int g_fp_n = 0;
+void pml_fpguard::note(unsigned v) {
+    v &= ~0x3Fu;                                   // control bits only (the low six are sticky exception flags)
+    std::lock_guard<std::mutex> lk(g_fp_mu);
+    for (int i = 0; i < g_fp_n; ++i) if (g_fp_seen[i] == v) return;
+    if (g_fp_n < 16) g_fp_seen[g_fp_n++] = v;
+}
+
 extern "C" {
 
-const char *pml_version(void) { return "peprml 0.1 (gfx950)"; }
+const char *pml_version(void) { return "peprml 0.2 (gfx950)"; }
+/* diagnostic: the distinct MXCSR control states (exception flags masked out) callers entered the library with */
+int pml_debug_fpenv(unsigned *values, int cap) {
+    std::lock_guard<std::mutex> lk(g_fp_mu);
+    for (int i = 0; i < g_fp_n && i < cap; ++i) values[i] = g_fp_seen[i];
+    return g_fp_n;
+}
 
 const char *pml_strerror(int code) {
     switch (code) {
@@ -71,6 +85,7 @@ static char *dup_string(const std::string &s) {
 // ---- resident batches ---------------------------------------------------------------------
 static int batch_create_impl(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks,
                              const pml_model *model, bool score_only, pml_batch **out) {
+    pml_fpguard fpg;
     if (!ctx || !out || !alns || n <= 0) return PML_EINVAL;
     *out = nullptr;
     pml_batch *b = new (std::nothrow) pml_batch();
@@ -118,16 +133,19 @@ int pml_batch_npatterns(const pml_batch *b, int g) {
 
 int pml_batch_score(pml_batch *b, double *lnl) {
     if (!b || !lnl) return PML_EINVAL;
+    pml_fpguard fpg;
     LOCKED(b);
     GUARD(b->b.score(std::vector<char>(), lnl));
 }
 int pml_batch_site_lnl(pml_batch *b, int g, double *out) {
     if (!b || !out || g < 0 || g >= (int)b->b.genes.size()) return PML_EINVAL;
+    pml_fpguard fpg;
     LOCKED(b);
     GUARD(b->b.site_lnl(g, out));
 }
 int pml_batch_set_alpha(pml_batch *b, int g, double alpha) {
     if (!b || g >= (int)b->b.genes.size() || !(alpha > 0)) return PML_EINVAL;
+    pml_fpguard fpg;
     LOCKED(b);
     if (g < 0) for (int i = 0; i < (int)b->b.genes.size(); ++i) b->b.set_alpha(i, alpha);
     else b->b.set_alpha(g, alpha);
@@ -135,11 +153,13 @@ int pml_batch_set_alpha(pml_batch *b, int g, double alpha) {
 }
 int pml_batch_root_derivs(pml_batch *b, double *lnl, double *d1, double *d2) {
     if (!b || !lnl || !d1 || !d2) return PML_EINVAL;
+    pml_fpguard fpg;
     LOCKED(b);
     GUARD(b->b.root_derivs(lnl, d1, d2));
 }
 int pml_batch_optimize(pml_batch *b, const pml_search_opts *opts, double *lnl, double *alpha) {
     if (!b || !lnl) return PML_EINVAL;
+    pml_fpguard fpg;
     LOCKED(b);
     const bool oa = opts ? opts->optimize_alpha != 0 : true;
     const double eps = (opts && opts->epsilon > 0) ? opts->epsilon : 1e-4;
@@ -152,6 +172,7 @@ int pml_batch_optimize(pml_batch *b, const pml_search_opts *opts, double *lnl, d
 }
 int pml_batch_search(pml_batch *b, const pml_search_opts *opts, double *lnl, double *alpha) {
     if (!b || !lnl) return PML_EINVAL;
+    pml_fpguard fpg;
     LOCKED(b);
     int rc;
     try { rc = opts ? b->b.set_constraints(opts->nconstraints, opts->constraint_ntax, opts->constraint_names, opts->constraint_rows) : 0;
@@ -165,6 +186,7 @@ int pml_batch_search(pml_batch *b, const pml_search_opts *opts, double *lnl, dou
 }
 int pml_batch_newick(pml_batch *b, int g, int digits, char **out) {
     if (!b || !out || g < 0 || g >= (int)b->b.genes.size()) return PML_EINVAL;
+    pml_fpguard fpg;
     LOCKED(b);
     const Gene &G = b->b.genes[g];
     *out = dup_string(G.tree.newick(G.aln.names, digits));
@@ -236,6 +258,7 @@ static int oneshot_chunk(pml_ctx *ctx, int op, int n, const pml_alignment *alns,
 static int oneshot(pml_ctx *ctx, int op, int n, const pml_alignment *alns, const char *const *newicks,
                    const pml_model *model, const pml_search_opts *opts, int flags, pml_result *out) {
     if (!ctx || !alns || !out || n <= 0) return PML_EINVAL;
+    pml_fpguard fpg;                               // also when this thread is the leader running other callers' requests
     for (int i = 0; i < n; ++i) std::memset(&out[i], 0, sizeof(pml_result));
     if (op != OP_SEARCH) {
         if (!newicks) return ctx->c.fail(PML_EINVAL, "newick required");
@@ -394,6 +417,7 @@ int pml_support_tree(const char *main_newick, int ntrees, const char *const *sup
 int pml_sh_support_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks, const pml_model *model,
                          int nboot, unsigned long long seed, pml_result *out) {
     if (!ctx || !alns || !newicks || !out || n <= 0 || nboot <= 0) return PML_EINVAL;
+    pml_fpguard fpg;
     for (int i = 0; i < n; ++i) { std::memset(&out[i], 0, sizeof(pml_result)); if (!newicks[i]) return ctx->c.fail(PML_EINVAL, "newick required"); }
     std::lock_guard<std::mutex> lk(ctx->c.mu);
     pml_batch *b = nullptr;
@@ -428,6 +452,7 @@ int pml_sh_support(pml_ctx *ctx, const pml_alignment *aln, const char *newick, c
 int pml_gamma20_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks, const pml_model *model,
                       pml_result *out, double *rescale_out) {
     if (!ctx || !alns || !newicks || !out || n <= 0) return PML_EINVAL;
+    pml_fpguard fpg;
     for (int i = 0; i < n; ++i) { std::memset(&out[i], 0, sizeof(pml_result)); if (!newicks[i]) return ctx->c.fail(PML_EINVAL, "newick required"); }
     std::lock_guard<std::mutex> lk(ctx->c.mu);
     pml_batch *b = nullptr;
@@ -477,6 +502,7 @@ int pml_refine_next(const char *newick, int cutoff, int ndone, const char *const
 
 int pml_parsimony_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const pml_parsimony_opts *opts, pml_result *out, long long *mp_length) {
     if (!ctx || !alns || !out || n <= 0) return PML_EINVAL;
+    pml_fpguard fpg;
     std::lock_guard<std::mutex> lk(ctx->c.mu);
     for (int i = 0; i < n; ++i) std::memset(&out[i], 0, sizeof(pml_result));
     try {

@@ -13,3 +13,17 @@ struct pml_ctx {
     long long coalesced_batches = 0, coalesced_requests = 0;
 };
 struct pml_batch { pml::Batch b; pml_ctx *owner; };
+
+// Floating-point control state.  The host side of the engine (Gamma quantiles, Brent, NJ, Newick printing) runs on the
+// CALLER's thread -- a JVM worker, a Python thread -- and must not inherit that thread's MXCSR (flush-to-zero / denormals-
+// are-zero / rounding mode): a last-bit change in a Gamma rate changes a likelihood in the 16th digit, and the optimisers'
+// discrete decisions (Brent brackets, dirty-branch flags) amplify that into visibly different -- equally valid -- optima.
+// Every computing entry point of the C ABI runs under the default state (round to nearest, no FTZ / DAZ, exceptions masked)
+// and restores the caller's on return.  pml_debug_fpenv reports the states callers came in with.
+#include <xmmintrin.h>
+struct pml_fpguard {
+    unsigned saved;
+    pml_fpguard() : saved(_mm_getcsr()) { note(saved); _mm_setcsr(0x1F80u); }
+    ~pml_fpguard() { _mm_setcsr((saved & ~0x3Fu) | (_mm_getcsr() & 0x3Fu)); }     // keep the exception flags raised meanwhile
+    static void note(unsigned v);
+};

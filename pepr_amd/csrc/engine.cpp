@@ -99,11 +99,40 @@ void Ctx::resolve_events() {
 // Batch: creation / layout
 // ------------------------------------------------------------------------------------------
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// PML_DET_LOG=<file>: every value the host consumes from the device (evaluations, Newton results) is recorded in memory
+// as a binary record and written out at process exit -- a determinism diagnostic (tools/dbg_detlog_diff.py) whose cost per
+// record is a few stores, so it does not perturb the timing it is meant to observe; off unless the variable is set
+struct DetRec { int batch, ntax, npat, nsites, kind, a, b, pad; double x, y, z; };
+static std::vector<DetRec> *g_det = nullptr;
+static std::mutex g_det_mu;
+static bool det_on() {
+    static const bool on = [] {
+        const char *p = std::getenv("PML_DET_LOG");
+        if (!p) return false;
+        g_det = new std::vector<DetRec>(); g_det->reserve(1 << 22);
+        std::atexit([] {
+            const char *q = std::getenv("PML_DET_LOG"); FILE *f = q ? std::fopen(q, "w") : nullptr;
+            if (!f) return;
+            for (const DetRec &r : *g_det) std::fprintf(f, "B%d g%d_%d_%d %c %d %d %a %a %a\n", r.batch, r.ntax, r.npat, r.nsites, (char)r.kind, r.a, r.b, r.x, r.y, r.z);
+            std::fclose(f);
+        });
+        return true;
+    }();
+    return on;
+}
+void det_record(int batch, const Gene &G, char kind, int a, int b, double x, double y, double z) {
+    if (!det_on()) return;
+    std::lock_guard<std::mutex> lk(g_det_mu);
+    g_det->push_back(DetRec{batch, G.aln.ntax, G.aln.npat, G.aln.nsites, kind, a, b, 0, x, y, z});
+}
+static std::atomic<int> g_batch_id{0};
 static double now_ms();
 
 int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *const *newicks, int pm, int nc,
                   double alpha, bool score_only) {
     ctx = c; pi_mode = pm; ncat = nc; score_only_batch = score_only;
+    det_id = ++g_batch_id;
     virtual_cherries = std::getenv("PML_NO_CHERRY") == nullptr;
     virtual_pitch = virtual_cherries && std::getenv("PML_NO_PITCH") == nullptr;
     if (n <= 0) return ctx->fail(-1, "empty batch");
@@ -191,8 +220,14 @@ int Batch::layout(double alpha, bool score_only) {
     }
     // results (8 doubles per gene) are written by the kernels straight into mapped pinned host
     // memory: no device-to-host copy node per step
-    HIPCHK(hipHostMalloc((void **)&h_scalars, sizeof(double) * 8 * MAXTAIL * n, hipHostMallocMapped));
-    HIPCHK(hipHostGetDevicePointer((void **)&d_scalars, h_scalars, 0));
+    // Results (8 doubles per gene and tail slot) live in DEVICE memory and reach the host by an explicit copy on the engine's
+    // stream before every synchronisation (fetch_results).  Rounds 1-2 let the kernels store them straight into mapped host
+    // memory; the explicit copy keeps PCIe writes out of the kernels and makes the hand-over an ordinary stream operation
+    // (it was one of the suspects of the reproducibility hunt of DESIGN.md 9 r02-g and changed nothing there).
+    scalars_doubles = (size_t)8 * MAXTAIL * n;
+    HIPCHK(hipMalloc((void **)&d_scalars, sizeof(double) * scalars_doubles));
+    HIPCHK(hipHostMalloc((void **)&h_scalars, sizeof(double) * scalars_doubles, hipHostMallocDefault));
+    std::memset(h_scalars, 0, sizeof(double) * scalars_doubles);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (std::getenv("PML_TRACE")) fprintf(stderr, "[pml] layout: arena %.1f GiB allocated + uploaded in %.1f ms\n", (double)total / (1 << 30), now_ms() - t_alloc0);
     return 0;
@@ -219,7 +254,9 @@ void Batch::destroy() {
     if (plan.d) hipFree(plan.d);
     plan = Plan();
     if (h_scalars) hipHostFree(h_scalars);
+    if (d_scalars) hipFree(d_scalars);
     if (h_chain) hipHostFree(h_chain);
+    if (d_chain) hipFree(d_chain);
     if (d_lenpool) hipFree(d_lenpool);
     if (d_tailpool) { hipFree(d_tailpool); d_tailpool = nullptr; tailpool_cap = 0; }
     if (d_site2pat) { hipFree(d_site2pat); d_site2pat = nullptr; }
@@ -329,8 +366,17 @@ int Batch::create_replicates(Ctx *c, const GeneStore &store, const std::vector<s
     return 0;
 }
 
+// device -> host copy of the result buffers, enqueued behind the kernels that write them; the caller synchronises
+int Batch::fetch_results(bool pooled) {
+    HIPCHK(hipMemcpyAsync(h_scalars, d_scalars, sizeof(double) * scalars_doubles, hipMemcpyDeviceToHost, ctx->stream));
+    if (pooled && results_used > 0 && d_chain)
+        HIPCHK(hipMemcpyAsync(h_chain, d_chain, sizeof(double) * 4 * results_used, hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
 int Batch::chain_sync() {
     if (int rc = flush_deferred()) return rc;
+    if (lanes_active) HIPCHK(hipStreamSynchronize(ctx->stream2));      // lane 1's results must be complete before the copy
+    if (int rc = fetch_results(true)) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream2));
     HIPCHK(hipGetLastError());
@@ -341,12 +387,14 @@ int Batch::chain_sync() {
 int Batch::ensure_results(size_t nresults) {
     if (nresults > chain_cap) {
         if (h_chain) hipHostFree(h_chain);
+        if (d_chain) hipFree(d_chain);
         h_chain = d_chain = nullptr; chain_cap = 0;
         const size_t cap = nresults * 3 / 2 + 64;
-        HIPCHK(hipHostMalloc((void **)&h_chain, cap * 4 * sizeof(double), hipHostMallocMapped));
-        HIPCHK(hipHostGetDevicePointer((void **)&d_chain, h_chain, 0));
+        HIPCHK(hipMalloc((void **)&d_chain, cap * 4 * sizeof(double)));
+        HIPCHK(hipHostMalloc((void **)&h_chain, cap * 4 * sizeof(double), hipHostMallocDefault));
         chain_cap = cap;
     }
+    results_used = nresults;
     return 0;
 }
 int Batch::ensure_tailpool(size_t bytes) {
@@ -514,6 +562,9 @@ int Batch::flush_deferred() {
     const hipStream_t cs = deferred.front().lane ? ctx->stream2 : ctx->stream;
     HIPCHK(hipMemcpyAsync((char *)d_stage + lo, (char *)h_stage + lo, hi - lo, hipMemcpyHostToDevice, cs));
     const ModelDev *md = ctx->d_model[pi_mode];
+    static const bool serialize = std::getenv("PML_SERIALIZE") != nullptr;      // diagnostic: a host sync after every launch
+#define PML_SER() do { if (serialize) hipStreamSynchronize(st); } while (0)
+    if (serialize) hipStreamSynchronize(cs);
     for (const Deferred &L : deferred) {
         const hipStream_t st = L.lane ? ctx->stream2 : ctx->stream;
         double *const frags_buf = L.lane ? d_frags2 : d_frags;
@@ -522,28 +573,29 @@ int Batch::flush_deferred() {
         if (L.nreq) {
             ctx->tic(K_PMAT, (double)L.nreq * PFRAG * 8);
             launch_pmat(md, (const PmatReq *)(ds + L.o_req), frags_buf, (int)L.nreq, st);
-            ctx->toc();
+            ctx->toc(); PML_SER();
         }
         if (L.nruns) {
             ctx->tic(K_NEWVIEW, L.algo_bytes);
             launch_oplist((const NvOp *)(ds + L.o_ops), (const GeneRun *)(ds + L.o_runs), (int)L.nruns, L.max_mpad, L.any_pitch, st);
-            ctx->toc();
+            ctx->toc(); PML_SER();
         }
         if (L.stagger) hipEventRecord(ev_stagger, st);
         if (L.neval) {
             ctx->tic(K_REDUCE, 0);
             launch_reduce((const ReduceReq *)(ds + L.o_red), (int)L.neval, st);
-            ctx->toc();
+            ctx->toc(); PML_SER();
         }
         if (L.nnewton) {
             ctx->tic(K_NEWTON, L.newton_bytes);
             launch_newton(md, (const NewtonReq *)(ds + L.o_newt), (int)L.nnewton, L.newton_maxm, st);
-            ctx->toc();
+            ctx->toc(); PML_SER();
         }
         ctx->tic_stream = nullptr;
     }
     deferred.clear();
-    flush_quota = std::min<size_t>(flush_quota * 2, 8);
+    static const size_t flush_max = std::getenv("PML_FLUSH_MAX") ? (size_t)std::atoi(std::getenv("PML_FLUSH_MAX")) : 8;      // A-B arm
+    flush_quota = std::min<size_t>(flush_quota * 2, flush_max);
     return 0;
 }
 
@@ -814,6 +866,9 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     const double t_launched = now_ms();
     ctx->stats[K_HOST_BUILD].launches++; ctx->stats[K_HOST_BUILD].ms += t_launched - t_begin;
     if (!chain) {
+        bool pooled = false;
+        for (auto &t : tails) pooled = pooled || t.result_host != nullptr;
+        if (int rc = fetch_results(pooled)) return rc;
         HIPCHK(hipStreamSynchronize(ctx->stream));
         HIPCHK(hipGetLastError());
         const double t_done = now_ms();
@@ -880,6 +935,7 @@ int Batch::replay_plan(double *lnl) {
     const double t_launched = now_ms();
     ctx->stats[K_HOST_BUILD].launches++; ctx->stats[K_HOST_BUILD].ms += t_launched - t_begin;
     if (!chain) {
+        if (int rc = fetch_results(false)) return rc;
         HIPCHK(hipStreamSynchronize(ctx->stream));
         HIPCHK(hipGetLastError());
         const double t_done = now_ms();
@@ -888,6 +944,7 @@ int Batch::replay_plan(double *lnl) {
     }
     for (auto &o : P.outs) genes[o.first].valid[o.second] = 1;
     for (size_t g = 0; g < genes.size(); ++g) lnl[g] = res((int)g)[0];
+    for (size_t g = 0; g < genes.size(); ++g) det_record(det_id, genes[g], 'R', 0, 0, lnl[g], genes[g].alpha, 0);
     return 0;
 }
 
@@ -906,6 +963,7 @@ int Batch::evaluate(const std::vector<char> &active, double *lnl) {
     }
     if (int rc = run(ops, tails)) return rc;
     for (auto &t : tails) lnl[t.gene] = res(t.gene)[0];
+    for (auto &t : tails) det_record(det_id, genes[t.gene], 'E', 0, 0, lnl[t.gene], genes[t.gene].alpha, 0);
     return 0;
 }
 int Batch::score(const std::vector<char> &active, double *lnl) {
@@ -1053,6 +1111,7 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
         for (auto &d : done) {
             Gene &G = genes[d.gene];
             const double nl = h_chain[4 * d.idx], dl = std::fabs(nl - d.old);
+            det_record(det_id, G, 'S', d.v, d.w, d.old, nl, h_chain[4 * d.idx + 1]);
             maxdelta[d.gene] = std::max(maxdelta[d.gene], dl);
             G.tree.set_len(d.v, d.w, nl);
             if (dl > thr) { std::swap(G.dirty, next[d.gene]); G.mark_node(d.v); G.mark_node(d.w); std::swap(G.dirty, next[d.gene]); }
@@ -1110,6 +1169,8 @@ int Batch::gamma20(std::vector<double> &lnl20, std::vector<double> &alpha20, std
         if (!k) return 0;
         HIPCHK(hipMemcpyAsync(d_stage, h_stage, (size_t)k * sizeof(G20Req), hipMemcpyHostToDevice, ctx->stream));
         launch_g20((const G20Req *)d_stage, k, ctx->stream);
+        results_used = (size_t)n;
+        if (int rc = fetch_results(true)) return rc;
         HIPCHK(hipStreamSynchronize(ctx->stream));
         HIPCHK(hipGetLastError());
         for (int g : who) { f[g] = -h_chain[4 * g]; if (!std::isfinite(f[g])) return ctx->fail(-5, "device returned a non-finite Gamma20 likelihood"); }

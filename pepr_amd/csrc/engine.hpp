@@ -73,6 +73,8 @@ struct Gene {
     void mark_none() { dirty.assign((size_t)tree.nnodes() * 3, 0); }
 };
 
+void det_record(int batch, const Gene &G, char kind, int a, int b, double x, double y, double z);   // PML_DET_LOG diagnostic (engine.cpp)
+
 struct pml_alignment_view { int ntax, nsites; const char *const *names; const char *const *rows; };
 
 // gene alignments encoded ONCE and kept in HBM; replicates (gene subsets) are gathered from them on the device
@@ -94,7 +96,7 @@ struct PendingOp { int gene, out_kind, out_id, level; Side child[2]; double t[2]
 
 struct Batch {
     Ctx *ctx = nullptr;
-    int pi_mode = 0, ncat = 4;
+    int pi_mode = 0, ncat = 4, det_id = 0;
     double newton_tol = 1e-8;      // Newton stop |dt| < tol: 1e-8 fine, 1e-6 in coarse phases
     std::vector<Gene> genes;
     char *arena = nullptr; size_t arena_bytes = 0;
@@ -106,7 +108,9 @@ struct Batch {
     double *d_nsync2 = nullptr; size_t nsync_cap2 = 0;
     int lane = 0;                                        // which stream / buffers the next run() uses (chained passes)
     hipEvent_t ev_stagger = nullptr; bool record_stagger = false;   // lane 1 starts one k_oplist behind lane 0
-    double *d_scalars = nullptr; double *h_scalars = nullptr;   // 8 doubles per gene
+    double *d_scalars = nullptr; double *h_scalars = nullptr;   // 8 doubles per gene and tail slot: device buffer + pinned host mirror
+    size_t scalars_doubles = 0, results_used = 0;
+    int fetch_results(bool pooled);                              // enqueue the device -> host copies of the result buffers
     double *d_nsync = nullptr; size_t nsync_cap = 0;             // Newton inter-workgroup sync blocks
     // cached descriptors of the full-traversal score of ALL genes (topology unchanged): replays skip
     // the tree walk and the descriptor build; transition matrices, CLVs and lnL are recomputed
@@ -136,7 +140,7 @@ struct Batch {
     std::vector<Deferred> deferred; size_t flush_quota = 1; bool lanes_active = false;
     int flush_deferred();
     int chain_begin(size_t nresults);
-    int ensure_results(size_t nresults);   // h_chain / d_chain: 4 mapped doubles per pooled Newton result
+    int ensure_results(size_t nresults);   // d_chain (device) / h_chain (pinned mirror): 4 doubles per pooled result
     // pooled sumtables for launches that carry more Newton requests per gene than MAXTAIL (all edges of an NNI round)
     char *d_tailpool = nullptr; size_t tailpool_cap = 0;
     int ensure_tailpool(size_t bytes);

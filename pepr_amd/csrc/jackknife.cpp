@@ -65,6 +65,7 @@ extern "C" int pml_concatenate(int ngenes, const pml_alignment *genes, int nsel,
 extern "C" int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *genes, const pml_model *model,
                              const pml_jackknife_opts *opts, pml_result *main_out, char **support_out) {
     if (!ctx || !genes || ngenes <= 0 || !main_out) return PML_EINVAL;
+    pml_fpguard fpg;
     std::memset(main_out, 0, sizeof *main_out);
     if (support_out) *support_out = nullptr;
     const int reps = opts ? opts->reps : 100;
@@ -169,6 +170,7 @@ extern "C" int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *gene
 extern "C" int pml_bootstrap(pml_ctx *ctx, const pml_alignment *aln, const pml_model *model, int reps, unsigned long long seed,
                              int spr_radius_best, double epsilon, pml_result *best_out, char **replicate_newicks_out) {
     if (!ctx || !aln || !best_out || reps < 0 || aln->ntax < 3 || aln->nsites < 1) return PML_EINVAL;
+    pml_fpguard fpg;
     std::memset(best_out, 0, sizeof *best_out);
     if (replicate_newicks_out) *replicate_newicks_out = nullptr;
     const double eps = epsilon > 0 ? epsilon : 1e-3;

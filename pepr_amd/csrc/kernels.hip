@@ -26,6 +26,7 @@
 // RAxML 7.2.5, SURVEY.md section 8a-11 iii-v).
 #include "kernels.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace pml {
@@ -43,6 +44,15 @@ __device__ __forceinline__ unsigned code_mask(unsigned code) {
     return code < 20u ? (1u << code) : (code == 20u ? 0xCu : (code == 21u ? 0x60u : 0xFFFFFu));
 }
 
+template <int CTRL>           // DPP quad_perm: 0xB1 = [1,0,3,2] (lane ^ 1), 0x4E = [2,3,0,1] (lane ^ 2)
+__device__ __forceinline__ double quad_swap(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_sum(double v) { v += quad_swap<0xB1>(v); v += quad_swap<0x4E>(v); return v; }
+
 // fragment element e = 4*k + i of fragment (c, st, kk) holds M_c[4 st + i][4 kk + k]
 __device__ __forceinline__ void frag_decode(int idx, int &c, int &row, int &col) {
     const int e = idx & 15, f = idx >> 4;          // f = c*25 + st*5 + kk
@@ -52,76 +62,90 @@ __device__ __forceinline__ void frag_decode(int idx, int &c, int &row, int &col)
 }
 
 // ------------------------------------------------------------------------------------------
-// k_pmat: P(t r_c) = U diag(exp(lambda t r_c)) U^-1, written directly in MFMA A-fragment order
+// k_pmat: P(t r_c) = U diag(exp(lambda t r_c)) U^-1 for all four categories of a request, ON THE MATRIX PIPE.
+// One wave per request (persistent: a wave walks requests w, w + W, ...).  v_mfma_f64_4x4x4_4b computes four independent
+// 4x4x4 products per instruction: the four BLOCKS are the four rate categories, so one instruction adds one k-step of one
+// 4x4 tile of P for every category at once:  D_c[i][j] += sum_k (U[4st+i][4kk+k] e_c[4kk+k]) * Uinv[4kk+k][4nt+j].
+// 25 tiles x 5 k-steps = 125 instructions per request (18 cycles each), against 32 k f64 FMAs on the vector pipe in the
+// round-1 kernel (one 320-thread block per request, two barriers, LDS staging: 0.122 ms for the 12.4 k requests of a C3
+// scoring step, 12 % of the step; VALU floor 0.05 ms).  The U / Uinv operands of a lane are the same for every request
+// and stay in 100 VGPRs; per request a lane needs 2 exponentials (80 per request, exchanged through a wave-private LDS
+// row) and 25 multiplies.  Lane map of the instruction (tools/probe_mfma444.hip): A[i][k]: i = lane&3, k = lane>>4;
+// B[k][j]: k = lane>>4, j = lane&3; D[i][j]: i = lane>>4, j = lane&3; block = (lane>>2)&3 throughout.
+// Outputs: PM_FRAGS / PM_FRAGS_PI in MFMA A-fragment order for k_oplist; PM_TIPTABLE T[c][code][q][kk] =
+// sum_{j in states(code)} P_c[4 kk + q][j] (the contraction of a tip's indicator vector, by lookup).
 // ------------------------------------------------------------------------------------------
-// One block per request.  Lane = matrix row (c, s) with W[k] = U[s][k] exp(lambda_k r_c t) in registers; each wave
-// produces five columns j, whose U^-1 column is wave-uniform and arrives by scalar loads (no LDS read per FMA).
-// PM_FRAGS / PM_FRAGS_PI write MFMA A-fragment order; PM_TIPTABLE writes T[c][code][s] =
-// sum_{j in states(code)} P_c[s][j] (the contraction of a tip's indicator vector, by lookup).
-constexpr int PMAT_THREADS = 320;      // 5 waves: 4 x (rows 0..63, five columns each) + 1 x (rows 64..79, all 20 columns)
-__global__ __launch_bounds__(PMAT_THREADS) void k_pmat(const ModelDev *__restrict__ md,
-                                                       const PmatReq *__restrict__ reqs,
-                                                       double *__restrict__ frags, int n) {
-    __shared__ double e[NCAT * NS];
-    __shared__ double sP[NCAT * NS * NS];      // staging of the result (fragment order) / P itself for tip tables
-    __shared__ double sU[NS * (NS + 1)];       // U rows, stride 21
-    __shared__ double sUiT[NS * (NS + 1)];     // U^-1 columns, stride 21 (wave 4 only: its lanes work on different columns)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave index in an SGPR: the column loop below is wave-uniform
-    const PmatReq req = reqs[blockIdx.x];
-    for (int i = tid; i < NS * NS; i += PMAT_THREADS) { sU[(i / NS) * (NS + 1) + i % NS] = md->U[i]; sUiT[(i / NS) * (NS + 1) + i % NS] = md->UinvT[i]; }
-    const double tlen = req.tp ? *req.tp : req.t;
-    if (tid < NCAT * NS) e[tid] = exp(md->eval[tid % NS] * (tlen * req.rates[tid / NS]));
-    __syncthreads();
-    double *out = frags + (size_t)blockIdx.x * FRAG_STRIDE;
-    // The 80 x 20 outputs fill five waves completely (64-lane waves over 80 rows would need a second pass at 25 % lane
-    // use; PMC showed the kernel at a VALU floor of half its run time).  Waves 0-3: lane = row 0..63, columns 5 wv ..
-    // 5 wv + 4 -- the U^-1 column is wave-uniform and arrives by scalar loads (SGPR operand of the FMA).  Wave 4: lane =
-    // (row 64 + lane%16, column group lane/16), its U^-1 column comes from LDS.
-    const bool tail = wv == 4;
-    const int row = tail ? 64 + (lane & 15) : lane;
-    const int jbase = tail ? (lane >> 4) * 5 : wv * 5;
-    const int c = row / NS, s2 = row % NS;
-    double W[NS];
+constexpr int PMAT_THREADS = 256;
+__global__ __launch_bounds__(PMAT_THREADS, 2) void k_pmat(const ModelDev *__restrict__ md,
+                                                          const PmatReq *__restrict__ reqs,
+                                                          double *__restrict__ frags, int n) {
+    __shared__ double sE[PMAT_THREADS / 64][NCAT * NS];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i4 = lane & 3, k4 = lane >> 4, cb = (lane >> 2) & 3;
+    double Au[5][5], Bu[5][5];
 #pragma unroll
-    for (int k = 0; k < NS; ++k) W[k] = sU[s2 * (NS + 1) + k] * e[c * NS + k];
-    const double scale = req.kind == PM_FRAGS_PI ? md->pi[s2] : 1.0;
+    for (int a = 0; a < 5; ++a)
 #pragma unroll
-    for (int jj = 0; jj < 5; ++jj) {
-        const int j = jbase + jj;
-        double v = 0.0;
-        if (tail) {
-#pragma unroll
-            for (int k = 0; k < NS; ++k) v += W[k] * sUiT[j * (NS + 1) + k];
-        } else {
-            const double *__restrict__ col = md->UinvT + (wv * 5 + jj) * NS;
-#pragma unroll
-            for (int k = 0; k < NS; ++k) v += W[k] * col[k];
+        for (int b = 0; b < 5; ++b) {
+            Au[a][b] = md->U[(4 * a + i4) * NS + 4 * b + k4];          // [st][kk]
+            Bu[a][b] = md->Uinv[(4 * a + k4) * NS + 4 * b + i4];       // [kk][nt]
         }
-        if (v < 0.0) v = 0.0;
-        if (req.kind == PM_TIPTABLE) sP[row * NS + j] = v;
-        // fragment element (c, st = s/4, kk = j/4)[4*(j%4) + s%4]: staged in LDS, written out coalesced below
-        else sP[((c * 25 + (s2 >> 2) * 5 + (j >> 2)) << 4) + ((j & 3) << 2) + (s2 & 3)] = v * scale;
-    }
-    __syncthreads();
-    if (req.kind != PM_TIPTABLE) {
-        for (int idx = tid; idx < PFRAG; idx += PMAT_THREADS) out[idx] = sP[idx];
-        return;
-    }
-    for (int idx = tid; idx < TIPTAB_DOUBLES; idx += PMAT_THREADS) {
-        const int kk = idx % TIPTAB_KK, rec = idx / TIPTAB_KK, q = rec & 3, code = (rec >> 2) % NCODES, c2 = (rec >> 2) / NCODES;
-        double v = 0.0;
-        if (kk < 5) {
-            const double *prow = sP + (c2 * NS + 4 * kk + q) * NS;
-            if (code < NS) v = prow[code];                          // a plain state: one column
-            else if (code == 20) v = prow[2] + prow[3];             // B = N | D  (same order as code_mask's bit walk)
-            else if (code == 21) v = prow[5] + prow[6];             // Z = Q | E
-            else {
+    // exponentials: lane l owns table rows l and (l < 16) 64 + l; row r = category r / 20, eigenvalue r % 20
+    const double lam0 = md->eval[lane % NS], lam1 = md->eval[(64 + (lane & 15)) % NS];
+    const int cat0 = lane / NS, cat1 = (64 + (lane & 15)) / NS;
+    const double pi_row[5] = {md->pi[k4], md->pi[4 + k4], md->pi[8 + k4], md->pi[12 + k4], md->pi[16 + k4]};   // D row = 4 st + (lane>>4)
+    const int nwaves = gridDim.x * (PMAT_THREADS / 64);
+    for (int rq = blockIdx.x * (PMAT_THREADS / 64) + wv; rq < n; rq += nwaves) {
+        const PmatReq &req = reqs[rq];
+        const double tlen = req.tp ? *req.tp : req.t;
+        const int kind = req.kind;
+        double *sEw = sE[wv];
+        sEw[lane] = exp(lam0 * (tlen * req.rates[cat0]));
+        if (lane < 16) sEw[64 + lane] = exp(lam1 * (tlen * req.rates[cat1]));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double ek[5];
 #pragma unroll
-                for (int j = 0; j < NS; ++j) v += prow[j];          // gap / unknown: every state
+        for (int kk = 0; kk < 5; ++kk) ek[kk] = sEw[cb * NS + 4 * kk + k4];
+        __builtin_amdgcn_wave_barrier();                       // every lane has its five values before the row is rewritten
+        double *out = frags + (size_t)rq * FRAG_STRIDE;
+        double rowsum[5];                                      // tip table, code "any state": sum over the lane's columns
+#pragma unroll
+        for (int st = 0; st < 5; ++st) {
+            double a[5];
+#pragma unroll
+            for (int kk = 0; kk < 5; ++kk) a[kk] = Au[st][kk] * ek[kk];
+            double acc[5];
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) {
+                double d = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < 5; ++kk) d = mfma4(a[kk], Bu[kk][nt], d);
+                acc[nt] = d < 0.0 ? 0.0 : d;
+            }
+            if (kind != PM_TIPTABLE) {
+                const double scale = kind == PM_FRAGS_PI ? pi_row[st] : 1.0;
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt)                 // fragment (c, st, kk = nt), element 4 * (column in tile) + (row in tile)
+                    out[((cb * 25 + st * 5 + nt) << 4) + (i4 << 2) + k4] = acc[nt] * scale;
+            } else {
+                // T[c][code][q = row in tile][kk = st]; plain states: the lane's own element of column 4 nt + (lane&3)
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt)
+                    out[((cb * NCODES + 4 * nt + i4) * 4 + k4) * TIPTAB_KK + st] = acc[nt];
+                const double b01 = acc[0] + quad_swap<0xB1>(acc[0]);       // columns {0,1} / {2,3} of tile 0 pairwise
+                if (i4 == 2) out[((cb * NCODES + 20) * 4 + k4) * TIPTAB_KK + st] = b01;                  // B = N | D (columns 2, 3)
+                const double z12 = acc[1] + quad_swap<0xD8>(acc[1]);       // quad_perm [0,2,1,3]: lanes 1 and 2 exchange
+                if (i4 == 1) out[((cb * NCODES + 21) * 4 + k4) * TIPTAB_KK + st] = z12;                  // Z = Q | E (columns 5, 6)
+                rowsum[st] = quad_sum(acc[0] + acc[1] + acc[2] + acc[3] + acc[4]);
+                if (i4 == 0) out[((cb * NCODES + 22) * 4 + k4) * TIPTAB_KK + st] = rowsum[st];           // gap / unknown: every state
             }
         }
-        out[idx] = v;
+        if (kind == PM_TIPTABLE && i4 < 3) {                   // the padding slot kk = 5 of every record
+#pragma unroll 1
+            for (int code = i4; code < NCODES; code += 3) out[((cb * NCODES + code) * 4 + k4) * TIPTAB_KK + 5] = 0.0;
+        }
     }
 }
 
@@ -527,15 +551,6 @@ __device__ __forceinline__ u64 ld_granule(const u64 *p) {
     return __hip_atomic_load((const gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int CTRL>           // DPP quad_perm: 0xB1 = [1,0,3,2] (lane ^ 1), 0x4E = [2,3,0,1] (lane ^ 2)
-__device__ __forceinline__ double quad_swap(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double quad_sum(double v) { v += quad_swap<0xB1>(v); v += quad_swap<0x4E>(v); return v; }
-
 // wave-uniform double kept in an SGPR pair (the Newton state is identical in every lane; as VGPRs it would cost 16 of 64)
 __device__ __forceinline__ double uni(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
@@ -881,7 +896,9 @@ void launch_gather(const GatherSeg *segs, int nsegs, int max_npat, hipStream_t s
 }
 void launch_pmat(const ModelDev *model, const PmatReq *reqs, double *frags, int n, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_pmat, dim3(n), dim3(PMAT_THREADS), 0, s, model, reqs, frags, n);
+    const int per_block = PMAT_THREADS / 64;                  // one wave per request, persistent beyond 2 waves per SIMD
+    const int blocks = std::min((n + per_block - 1) / per_block, 512);
+    hipLaunchKernelGGL(k_pmat, dim3(blocks), dim3(PMAT_THREADS), 0, s, model, reqs, frags, n);
 }
 void launch_eigfrags(const ModelDev *model, double *frags2, hipStream_t s) {
     hipLaunchKernelGGL(k_eigfrags, dim3(1), dim3(256), 0, s, model, frags2);

@@ -247,7 +247,7 @@ int Batch::nni_round(const std::vector<char> &active, std::vector<double> &lnl, 
             if (!active[g] || e0 >= edges[g].size()) continue;
             size_t k = rbase[g];
             for (size_t e = e0; e < std::min(edges[g].size(), e0 + chunk); ++e)
-                for (int q = 0; q < 3; ++q, ++k) { Tn[g][3 * e + q] = h_chain[4 * k]; L[g][3 * e + q] = h_chain[4 * k + 1]; }
+                for (int q = 0; q < 3; ++q, ++k) { Tn[g][3 * e + q] = h_chain[4 * k]; L[g][3 * e + q] = h_chain[4 * k + 1]; det_record(det_id, genes[g], 'N', (int)e, q, h_chain[4 * k], h_chain[4 * k + 1], 0); }
         }
     }
     // candidate selection and application

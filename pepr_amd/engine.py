@@ -353,6 +353,16 @@ def rf_distance(newick_a, newick_b):
     return rf.value
 
 
+def fpenv_seen():
+    """MXCSR control states callers entered the library with (diagnostic; the library computes under the default state)."""
+    L = _lib.load()
+    if not hasattr(L, "pml_debug_fpenv"):          # an older build loaded through PEPRML_LIB (A/B runs)
+        return []
+    v = (C.c_uint * 16)()
+    n = L.pml_debug_fpenv(v, 16)
+    return [int(x) for x in v[:min(n, 16)]]
+
+
 def refine_next(supported_newick, cutoff=100, done=()):
     """Next clade to refine (PhylogeneticTreeRefiner.getNextIndexToRefine :298-359): (sorted leaf list or None,
     floor(mean descendant support) per node in order of appearance)."""
