@@ -294,7 +294,7 @@ static int oneshot(pml_ctx *ctx, int op, int n, const pml_alignment *alns, const
 // serialising such calls the first caller that finds no batch in flight becomes the leader: it takes every queued
 // request with the same operation / model / options, runs them as one device batch and wakes their owners.
 // Requests that arrive meanwhile form the next batch.  Blocking semantics and results are those of the
-// single call (batches are bit-reproducible whatever their composition).
+// single call (a gene's arithmetic does not depend on what shares its batch: tests/test_gpu_parity.py).
 struct pml_request {
     int op, flags; const pml_alignment *aln; const char *nw;
     pml_model model; pml_search_opts opts; pml_result *out;
