@@ -224,8 +224,8 @@ def main():
         # box start measured 1.07 s for the search that later takes 0.83 s, profiles/r02_ab_search_warmup.txt): the same
         # untimed step, repeated until CLOCK_WARMUP_S have passed
         t_w = time.perf_counter()
-        while ci == 0 and time.perf_counter() - t_w < CLOCK_WARMUP_S:
-            lnl = step(); clock_warmup_steps += 1
+        while ci == 0 and batch and time.perf_counter() - t_w < CLOCK_WARMUP_S:
+            batch.score(); clock_warmup_steps += 1          # no collective here: every rank loops on its own clock
         if ci == 0:
             ctx.kernel_stats(reset=True)
         if world > 1:
