@@ -914,14 +914,16 @@ int Batch::replay_plan(double *lnl) {
     PmatReq *hreq = (PmatReq *)((char *)P.h + P.o_req);
     std::vector<char> moved(genes.size(), 0);            // rates are rewritten only for genes whose alpha changed
     for (size_t g = 0; g < genes.size(); ++g) if (P.rates_seen[g] != genes[g].rates_epoch) { moved[g] = 1; P.rates_seen[g] = genes[g].rates_epoch; }
+    bool changed = false;                       // lengths and rates already on the device are not uploaded again
     for (size_t i = 0; i < P.nreq; ++i) {
         const ReqSrc &s = P.src[i];
         const Gene &G = genes[s.gene];
-        hreq[i].t = G.tree.len[s.v][s.q];
-        if (moved[s.gene]) std::memcpy(hreq[i].rates, G.rates, sizeof hreq[i].rates);
+        const double t = G.tree.len[s.v][s.q];
+        if (hreq[i].t != t) { hreq[i].t = t; changed = true; }
+        if (moved[s.gene]) { std::memcpy(hreq[i].rates, G.rates, sizeof hreq[i].rates); changed = true; }
     }
     char *ds = (char *)P.d;
-    HIPCHK(hipMemcpyAsync(ds + P.o_req, hreq, P.nreq * sizeof(PmatReq), hipMemcpyHostToDevice, ctx->stream));
+    if (changed) HIPCHK(hipMemcpyAsync(ds + P.o_req, hreq, P.nreq * sizeof(PmatReq), hipMemcpyHostToDevice, ctx->stream));
     const ModelDev *md = ctx->d_model[pi_mode];
     ctx->tic(K_PMAT, (double)P.nreq * PFRAG * 8);
     launch_pmat(md, (const PmatReq *)(ds + P.o_req), d_frags, (int)P.nreq, ctx->stream);
