@@ -894,7 +894,10 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             HIPCHK(hipHostMalloc(&P.h, bytes)); HIPCHK(hipMalloc(&P.d, bytes)); P.bytes = bytes;
         }
         std::memcpy(P.h, hs, bytes);
-        HIPCHK(hipMemcpy(P.d, ds, bytes, hipMemcpyDeviceToDevice));
+        // ON THE BATCH'S STREAM: a device-to-device hipMemcpy returns before the copy ran and the null stream is not
+        // ordered against the (non-blocking) stream a replay uploads its refreshed requests on -- the late copy then
+        // put the recorded rates back under the first replay (DESIGN r02-g: the cause of the rare different optimum)
+        HIPCHK(hipMemcpyAsync(P.d, ds, bytes, hipMemcpyDeviceToDevice, ctx->stream));
         P.o_req = o_req; P.o_ops = o_ops; P.o_runs = o_runs; P.o_red = o_red;
         P.nreq = ireq; P.nruns = nruns; P.neval = neval; P.max_mpad = max_mpad; P.algo_bytes = algo_bytes; P.any_pitch = any_pitch;
         P.rates_seen.resize(genes.size()); for (size_t g = 0; g < genes.size(); ++g) P.rates_seen[g] = genes[g].rates_epoch;
