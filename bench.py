@@ -213,13 +213,20 @@ def main():
         ids = [gene_ids[i] for i in idx] + [-1] * (len(chunks[0]) - len(idx))     # equal record counts per rank
 
         def step():
-            lnl = batch.score() if batch else np.zeros(0)
-            if world > 1:                      # the one gather of per-gene results (RCCL over xGMI)
-                pd.gather_results(ids, np.concatenate([lnl, np.zeros(len(ids) - len(lnl))]))
-            return lnl
+            return batch.score() if batch else np.zeros(0)          # ends with the results on this rank's host (synchronised)
+
+        def gather(lnls):
+            # THE one gather of per-gene results of a job (RCCL over xGMI): the K passes of the timed region are
+            # one job, their K x genes records go to rank 0 in ONE collective, inside the timed region.  (A gather per
+            # 1-ms pass would price the plumbing a thousand times higher than the real job does: one gather per tree build.)
+            if world > 1:
+                lnls = lnls or [np.zeros(0)]
+                k = len(lnls)
+                pd.gather_results(ids * k, np.concatenate([np.concatenate([l, np.zeros(len(ids) - len(l))]) for l in lnls]))
 
         for _ in range(args.warmup):
             lnl = step()
+        gather([lnl] if args.warmup else [])              # also brings the communicator up before the clock starts
         # a fresh box needs a second or so of load before the chip and the host hold their clocks (the first processes after
         # box start measured 1.07 s for the search that later takes 0.83 s, profiles/r02_ab_search_warmup.txt): the same
         # untimed step, repeated until CLOCK_WARMUP_S have passed
@@ -232,8 +239,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        timed = []
         for _ in range(args.steps):
-            lnl = step()
+            lnl = step(); timed.append(lnl)
+        gather(timed)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
