@@ -341,6 +341,11 @@ def main():
                 traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
                 traffic_src = "committed PMC passes, profiles/" + name
                 break
+        algo_flops = float(npat) / max(nchunks, 1) * (6480.0 * (ntax - 2) + 3360.0)      # one launch = one resident sub-batch of rank 0
+        pipe_busy = None
+        pb = os.path.join(ROOT, "profiles", "r02_pmc_k_oplist_chained_%s.json" % args.workload)
+        if os.path.exists(pb) and not strong:
+            pipe_busy = json.load(open(pb))["derived"]["mfma_pipe_busy_frac"]
         out = {
             "metric": "M site-lnL/sec (WAG+G4 full-tree likelihood evaluations x alignment patterns); the gene-trees/sec half of BASELINE.json's metric is search.gene_trees_per_sec",
             "value": tot_pat * args.steps / dt / 1e6, "unit": "M site-lnL/s",
@@ -351,12 +356,20 @@ def main():
                 args.workload, ("%d genes in all, block-cyclic by cost" % total) if strong else ("%d genes/GPU" % per_gpu), ntax, nsites),
                 "patterns_rank0": npat, "genes_total": total, "resident_sub_batches_per_rank": nchunks,
                 "parallelism": "gene-sharded x%d" % world},
-            # frac = SURVEY 8d algorithmic bytes / time / peak (counts CLVs that virtual cherries and pitchforks never
-            # materialise); frac_traffic = counter bytes / time / peak = the share of the HBM peak the kernel really streams
-            "roofline": {"bound": "hbm", "kernel": "k_oplist (newview+evaluate)", "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
-                         "frac_traffic": (traffic / (avg_ms * 1e-3) / 8e12) if (traffic and avg_ms > 0) else None,
-                         "avg_launch_ms": avg_ms, "algo_bytes_per_launch": nv["algo_bytes"] / max(nv["launches"], 1)},
+            # Since register chaining a scoring launch moves a fraction of SURVEY 8d's bytes (a child that
+            # its parent consumes next never leaves the registers), so the pass sits under SURVEY 8d's OTHER roofline, the
+            # f64 matrix pipe ("the fused scorer ... then the bound is flops"): achieved = 8d's flops per site-lnL
+            # (6480 (n-2) + 3360) x the patterns of a launch / the launch's HIP-event time; peak = 78.6 TFLOP/s (vendor FP64
+            # matrix figure SURVEY 8d uses; MI355X_MICROARCH.md lists none for f64; v_mfma_f64_4x4x4 measured 62-67 on the
+            # box, profiles/r01_ubench_f64.txt).  "hbm" keeps the previous accounting beside it: frac = 8d's bytes / time /
+            # 8 TB/s (above 1: bytes that are no longer moved), frac_traffic = counter bytes / time / 8 TB/s.
+            "roofline": {"bound": "mfma", "kernel": "k_oplist (newview+evaluate)", "achieved": algo_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
+                         "peak": 78.6, "unit": "TFLOP/s", "frac": (algo_flops / (avg_ms * 1e-3) / 78.6e12) if avg_ms > 0 else 0.0,
+                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms,
+                         "algo_flops_per_launch": algo_flops, "matrix_pipe_busy_frac_pmc": pipe_busy,
+                         "hbm": {"achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                                 "frac_traffic": (traffic / (avg_ms * 1e-3) / 8e12) if (traffic and avg_ms > 0) else None,
+                                 "algo_bytes_per_launch": nv["algo_bytes"] / max(nv["launches"], 1)}},
             "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in stats.items() if v["launches"]},
         }
         if search is not None:

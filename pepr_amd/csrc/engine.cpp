@@ -577,7 +577,7 @@ int Batch::flush_deferred() {
         }
         if (L.nruns) {
             ctx->tic(K_NEWVIEW, L.algo_bytes);
-            launch_oplist((const NvOp *)(ds + L.o_ops), (const GeneRun *)(ds + L.o_runs), (int)L.nruns, L.max_mpad, L.any_pitch, st);
+            launch_oplist((const NvOp *)(ds + L.o_ops), (const GeneRun *)(ds + L.o_runs), (int)L.nruns, L.max_mpad, L.any_pitch, L.any_chain, st);
             ctx->toc(); PML_SER();
         }
         if (L.stagger) hipEventRecord(ev_stagger, st);
@@ -620,7 +620,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
                                 if (t.mode >= MODE_EVALUATE && t.bv < 0) loose += 1; }
         nreq_max = std::min(nreq_max, keyed + loose);
     }
-    bool any_pitch = false;
+    bool any_pitch = false, any_chain = false;
     if (int rc = ensure_frags(std::max(nreq_max, (size_t)1))) return rc;
     double *&nsync_buf = lane ? d_nsync2 : d_nsync; size_t &nsync_c = lane ? nsync_cap2 : nsync_cap;
     if (nnewton > nsync_c) {
@@ -748,6 +748,23 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         GeneRun &run = hruns[nruns++];
         run.op_begin = (int)nout;
         max_mpad = std::max(max_mpad, mp);
+        // Register chaining (kernels.h OPF_CHAIN_*): the gene's last newview result is still in the registers of the wave
+        // that owns the patterns.  Every launch takes a child that the directly following operation of the gene consumes
+        // from there instead of reading it back; whole-tree scoring passes (record_plan), whose results nobody reads
+        // again, do not even write such a child (it stays invalid in memory and is recomputed if a later request wants it).
+        // PML_CHAIN (A-B switch): 2 = that (default), 1 = scoring passes only, 0 = off.  Measured on one box, rotated order
+        // (profiles/r02_ab_register_chaining.txt): C3 scoring launch 0.89 -> 0.72 ms, C4 shard 3.40 -> 2.92 ms, C3 search
+        // 153 -> 161 gene-trees/s.
+        static const int chain_env = std::getenv("PML_CHAIN") ? std::atoi(std::getenv("PML_CHAIN")) : 2;
+        const bool chain_reads = chain_env == 2 || (chain_env == 1 && record_plan), chain_nostore = chain_env >= 1 && record_plan;
+        long last_nv = -1, last_nv_op = -1;            // hops / ops index of the gene's last newview
+        auto chained_from = [&](const Side &sd, int kind) {
+            return chain_reads && last_nv >= 0 && kind == SK_CLV && sd.kind == ops[last_nv_op].out_kind && sd.id == ops[last_nv_op].out_id;
+        };
+        auto consume_last = [&]() {                     // the last newview's result is taken from the registers by the operation being built
+            any_chain = true;
+            if (chain_nostore) { hops[last_nv].flags |= OPF_NO_STORE; ops[last_nv_op].unstored = true; }
+        };
         auto emit_tail = [&](const Tail &t) -> int {
             NvOp &d = hops[nout++];
             std::memset(&d, 0, sizeof d);
@@ -755,6 +772,8 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             if (resolve(g, t.a, L) || resolve(g, t.b, R)) return ctx->fail(-5, "internal: tail message has no slot");
             d.l = L.s; d.r = R.s; d.l_scl = L.scl; d.r_scl = R.scl;
             d.flags = L.kind | (R.kind << 2); d.mpad = mp; d.mode = t.mode;
+            if (chained_from(t.a, L.kind)) { d.flags |= OPF_CHAIN_L; consume_last(); }
+            else if (t.mode >= MODE_EVALUATE && chained_from(t.b, R.kind)) { d.flags |= OPF_CHAIN_R; consume_last(); }
             double *result = t.result_dev ? t.result_dev : d_scalars + 8 * (g * MAXTAIL + t.slot);
             if (t.mode == MODE_EVALUATE_CAT) {
                 if (!t.patlnl_dev || !t.scl_dev) return ctx->fail(-1, "internal: table slice missing");
@@ -820,8 +839,13 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
                 }
                 pm[c] = add_req(g, o.t[c], PM_FRAGS, bv, bq);
             }
+            // the child that is the gene's previous result goes LEFT (the two factors of a newview commute bit for bit)
+            if (chained_from(o.child[1], S[1].kind)) { std::swap(S[0], S[1]); std::swap(pm[0], pm[1]); std::swap(o.child[0], o.child[1]); }
+            d.flags = S[0].kind | (S[1].kind << 2);
+            if (chained_from(o.child[0], S[0].kind)) { d.flags |= OPF_CHAIN_L; consume_last(); }
             d.l = S[0].s; d.r = S[1].s; d.l_scl = S[0].scl; d.r_scl = S[1].scl; d.pl = pm[0]; d.pr = pm[1];
             algo_bytes += (double)G.aln.npat * (S[0].bytes + S[1].bytes + 640);
+            last_nv = (long)nout - 1; last_nv_op = (long)iop;
             ++emitted;
             if (int rc = flush_tails(false)) return rc;
         }
@@ -853,7 +877,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     Deferred L;
     L.base = base; L.bytes = bytes; L.o_req = o_req; L.o_ops = o_ops; L.o_runs = o_runs; L.o_red = o_red; L.o_newt = o_newt;
     L.nreq = ireq; L.nruns = nruns; L.neval = neval; L.nnewton = nnewton; L.max_mpad = max_mpad; L.newton_maxm = newton_maxm;
-    L.any_pitch = any_pitch; L.algo_bytes = algo_bytes; L.newton_bytes = newton_bytes; L.lane = lane; L.stagger = record_stagger;
+    L.any_pitch = any_pitch; L.any_chain = any_chain; L.algo_bytes = algo_bytes; L.newton_bytes = newton_bytes; L.lane = lane; L.stagger = record_stagger;
     record_stagger = false;
     // Inside a chained pass the upload + launches of a step are DEFERRED and issued in groups (1, 2, 4, 8, 8, ... steps):
     // a host-to-device copy between two kernels of one stream costs a ~20 us bubble on the compute queue (measured:
@@ -883,7 +907,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
                 return ctx->fail(-5, t.mode == MODE_EVALUATE ? "device returned a non-finite likelihood" : "k_newton: cross-workgroup exchange timed out (non-finite result)");
         }
     }
-    for (auto &o : ops) if (o.out_kind == SIDE_MSG) { Gene &G = genes[o.gene]; G.valid[o.out_id] = 1; G.pend_level[o.out_id] = -1; }
+    for (auto &o : ops) if (o.out_kind == SIDE_MSG) { Gene &G = genes[o.gene]; G.valid[o.out_id] = o.unstored ? 0 : 1; G.pend_level[o.out_id] = -1; }
     if (record_plan) {                       // keep the descriptors of this full-traversal score
         record_plan = false;
         Plan &P = plan;
@@ -899,10 +923,10 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         // put the recorded rates back under the first replay (DESIGN r02-g: the cause of the rare different optimum)
         HIPCHK(hipMemcpyAsync(P.d, ds, bytes, hipMemcpyDeviceToDevice, ctx->stream));
         P.o_req = o_req; P.o_ops = o_ops; P.o_runs = o_runs; P.o_red = o_red;
-        P.nreq = ireq; P.nruns = nruns; P.neval = neval; P.max_mpad = max_mpad; P.algo_bytes = algo_bytes; P.any_pitch = any_pitch;
+        P.nreq = ireq; P.nruns = nruns; P.neval = neval; P.max_mpad = max_mpad; P.algo_bytes = algo_bytes; P.any_pitch = any_pitch; P.any_chain = any_chain;
         P.rates_seen.resize(genes.size()); for (size_t g = 0; g < genes.size(); ++g) P.rates_seen[g] = genes[g].rates_epoch;
         P.src = last_src; P.outs.clear();
-        for (auto &o : ops) if (o.out_kind == SIDE_MSG) P.outs.push_back({o.gene, o.out_id});
+        for (auto &o : ops) if (o.out_kind == SIDE_MSG && !o.unstored) P.outs.push_back({o.gene, o.out_id});
         P.epoch = topo_epoch; P.valid = true;
     }
     return 0;
@@ -932,7 +956,7 @@ int Batch::replay_plan(double *lnl) {
     launch_pmat(md, (const PmatReq *)(ds + P.o_req), d_frags, (int)P.nreq, ctx->stream);
     ctx->toc();
     ctx->tic(K_NEWVIEW, P.algo_bytes);
-    launch_oplist((const NvOp *)(ds + P.o_ops), (const GeneRun *)(ds + P.o_runs), (int)P.nruns, P.max_mpad, P.any_pitch, ctx->stream);
+    launch_oplist((const NvOp *)(ds + P.o_ops), (const GeneRun *)(ds + P.o_runs), (int)P.nruns, P.max_mpad, P.any_pitch, P.any_chain, ctx->stream);
     ctx->toc();
     ctx->tic(K_REDUCE, 0);
     launch_reduce((const ReduceReq *)(ds + P.o_red), (int)P.neval, ctx->stream);

@@ -92,7 +92,8 @@ enum { SIDE_TIP = 0, SIDE_MSG = 1, SIDE_SCRATCH = 2, SIDE_CHERRY = 3, SIDE_PITCH
 struct Side { int kind, id; };
 // bv/bq (optional, scratch outputs): the tree branch (node, slot) child c's length belongs to -- lets run() share ONE
 // transition-matrix request among all operations of a launch that cross the same branch
-struct PendingOp { int gene, out_kind, out_id, level; Side child[2]; double t[2]; int bv[2] = {-1, -1}, bq[2] = {0, 0}; };
+struct PendingOp { int gene, out_kind, out_id, level; Side child[2]; double t[2]; int bv[2] = {-1, -1}, bq[2] = {0, 0};
+                   bool unstored = false; /* run(): the result stayed in registers (OPF_NO_STORE) and is not valid in memory */ };
 
 struct Batch {
     Ctx *ctx = nullptr;
@@ -119,7 +120,7 @@ struct Batch {
         bool valid = false; unsigned epoch = 0;
         void *h = nullptr, *d = nullptr; size_t bytes = 0;
         size_t o_req = 0, o_ops = 0, o_runs = 0, o_red = 0, nreq = 0, nruns = 0, neval = 0;
-        int max_mpad = 0; double algo_bytes = 0; bool any_pitch = false;
+        int max_mpad = 0; double algo_bytes = 0; bool any_pitch = false, any_chain = false;
         std::vector<ReqSrc> src; std::vector<std::pair<int, int>> outs;
         std::vector<unsigned> rates_seen;          // per gene: rates_epoch the descriptors carry
     } plan;
@@ -136,7 +137,7 @@ struct Batch {
     double *d_chain = nullptr, *h_chain = nullptr; size_t chain_cap = 0;     // 4 doubles per chained Newton result
     // a step of a chained pass whose upload + launches are issued later, grouped with its neighbours (flush_deferred)
     struct Deferred { size_t base, bytes, o_req, o_ops, o_runs, o_red, o_newt, nreq, nruns, neval, nnewton;
-                      int max_mpad, newton_maxm, lane; bool any_pitch, stagger; double algo_bytes, newton_bytes; };
+                      int max_mpad, newton_maxm, lane; bool any_pitch, any_chain, stagger; double algo_bytes, newton_bytes; };
     std::vector<Deferred> deferred; size_t flush_quota = 1; bool lanes_active = false;
     int flush_deferred();
     int chain_begin(size_t nresults);

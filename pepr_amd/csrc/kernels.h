@@ -58,6 +58,11 @@ enum { PM_FRAGS = 0, PM_FRAGS_PI = 1, PM_TIPTABLE = 2 };
 //               p0,p1,p2 = codes of a,b,c; t0,t1,t2 = their tip tables.
 enum { SK_CLV = 0, SK_TIP = 1, SK_CHERRY = 2, SK_PITCH = 3 };
 constexpr int OPF_NT_STORE = 16;
+// Register chaining (k_oplist<9>): a wave owns the same 32 patterns in every operation of its gene, so the result of one
+// newview is still in its registers when the next operation of the gene consumes it (post-order: a parent directly follows
+// its last-computed child).  OPF_CHAIN_L / OPF_CHAIN_R: that side (kind SK_CLV) is taken from the registers instead of being
+// read back; OPF_NO_STORE: the result is consumed that way only and is not written at all (whole-tree scoring).
+constexpr int OPF_CHAIN_L = 32, OPF_CHAIN_R = 64, OPF_NO_STORE = 128;
 struct OpSide {
     const void *p0, *p1, *p2;
     const double *t0, *t1, *t2;
@@ -74,7 +79,7 @@ struct NvOp {
     const double *pl;       // fragment sets (PFRAG doubles); null for a newview SK_TIP side
     const double *pr;
     int mpad;               // padded pattern count (multiple of 32)
-    int flags;              // bits 0-1: left side kind, bits 2-3: right side kind, OPF_NT_STORE: store the result non-temporally
+    int flags;              // bits 0-1: left side kind, bits 2-3: right side kind, OPF_*
     int mode;               // MODE_NEWVIEW / MODE_SUMTABLE / MODE_EVALUATE
     int pad;
     double *aux;            // sumtable ops: the Newton sync block to zero (NEWTON_SYNC_DOUBLES), else null
@@ -150,7 +155,7 @@ void launch_pmat(const ModelDev *model, const PmatReq *reqs, double *frags, int 
 //   set 0: x_i = sum_s pi_s U[s][i] A[s]     set 1: y_i = sum_j Uinv[i][j] B[j]
 void launch_eigfrags(const ModelDev *model, double *frags2, hipStream_t s);
 // any_pitch: some op has an SK_PITCH side (two more LDS fragment regions are allocated)
-void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, bool any_pitch, hipStream_t s);
+void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, bool any_pitch, bool chained, hipStream_t s);
 void launch_reduce(const ReduceReq *reqs, int n, hipStream_t s);
 void launch_newton(const ModelDev *model, const NewtonReq *reqs, int n, int max_mpad, hipStream_t s);
 

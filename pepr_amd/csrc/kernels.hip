@@ -283,9 +283,9 @@ __device__ __forceinline__ void load_pitch(Operand &o, const OpSide &sd, const d
 //   MODE_NEWVIEW : out[c][s] = (P_L,c . L_c)[s] * (P_R,c . R_c)[s], 2^256 rescue, scaling counts
 //   MODE_SUMTABLE: same contraction with the eigen-basis matrices (no rescue), counts = l + r
 //   MODE_EVALUATE: per-pattern ln( 1/4 sum_c sum_s L_c[s] (pi P_c . R_c)[s] ) - counts*256 ln 2
-template <bool PREFETCH>
+template <bool PREFETCH, bool CHAIN>
 __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restrict__ sP, const unsigned char *__restrict__ sT,
-                                         int p, int lane) {
+                                         int p, int lane, Operand (&X)[4], ivec2 &xsc) {
     // `op` refers to the descriptor in global memory (wave-uniform): fields are fetched by scalar loads
     // where they are used instead of being held in ~34 SGPRs for the whole op
     const int q = lane >> 4;
@@ -296,6 +296,10 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
     const int lk = op.flags & 3, rk = (op.flags >> 2) & 3;
     const bool nt_store = (op.flags & OPF_NT_STORE) != 0;      // wave-uniform: the result is not read again soon (host's call)
     const int mode = op.mode;
+    // register chaining (kernels.h OPF_CHAIN_*): X[0..3] = the four categories of the wave's last newview result, xsc its counts
+    const bool chL = CHAIN && (op.flags & OPF_CHAIN_L) != 0, chR = CHAIN && (op.flags & OPF_CHAIN_R) != 0;
+    const bool keep = !(CHAIN && (op.flags & OPF_NO_STORE) != 0);
+    constexpr bool PF_L = PREFETCH && !CHAIN;       // the chained variants prefetch the right side only (the chained child is the left one; registers)
     // (a plain tip side goes through the MFMA with its 0/1 indicator operand: the matrix pipe has slack and
     // table gathers for it measured slower)
     gcptr Lp = (gcptr)op.l.p0, Rp = (gcptr)op.r.p0;
@@ -319,14 +323,16 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
 
     Operand curL, curR, nxtL, nxtR;
     if (lk == SK_TIP) load_tip(curL, sT, cl, q);
-    else if (lk == SK_CLV) load_clv(curL, Lp, lane_off, rowbytes, 0);      // evaluate: left side in output layout
+    else if (lk == SK_CLV && !chL) load_clv(curL, Lp, lane_off, rowbytes, 0);      // evaluate: left side in output layout
     if (rk == SK_TIP) load_tip(curR, sT, cr, q);
-    else if (rk == SK_CLV) load_clv(curR, Rp, lane_off, rowbytes, 0);
+    else if (rk == SK_CLV && !chR) load_clv(curR, Rp, lane_off, rowbytes, 0);
 #pragma unroll 1
     for (int c = 0; c < NCAT; ++c) {
+        Operand Y;                                            // CHAIN: this category of the result
+        if (CHAIN) { if (chL) curL = X[0]; if (chR) curR = X[0]; }     // X is rotated once per category: X[0] is category c
         if (PREFETCH && c + 1 < NCAT) {                       // software prefetch of the next category
-            if (lk == SK_CLV) load_clv(nxtL, Lp, lane_off, rowbytes, c + 1);
-            if (rk == SK_CLV) load_clv(nxtR, Rp, lane_off, rowbytes, c + 1);
+            if (PF_L && lk == SK_CLV && !chL) load_clv(nxtL, Lp, lane_off, rowbytes, c + 1);
+            if (rk == SK_CLV && !chR) load_clv(nxtR, Rp, lane_off, rowbytes, c + 1);
         }
         if (lk == SK_CHERRY) load_cherry(curL, op.l, cl, cl2, c, q);
         else if (lk == SK_PITCH) load_pitch(curL, op.l, fLi, cl, cl2, cl3, c, q);
@@ -349,6 +355,8 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
             contract_stream(fR + c * 25 * 16, curR, [&](int st, double y0, double y1) {
                 const double o0 = aL[st][0] * y0, o1 = aL[st][1] * y1;
                 mx0 = fmax(mx0, o0); mx1 = fmax(mx1, o1);
+                if (CHAIN) Y.v[st] = (dvec2){o0, o1};
+                if (!keep) return;
                 // buffer stores: the cache policy is an immediate of the instruction, so the two policies are two instructions
                 // under a wave-uniform branch (an if/else of a plain and a __builtin_nontemporal_store is merged by hipcc
                 // into ONE plain store)
@@ -358,26 +366,37 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
                 else __builtin_amdgcn_raw_buffer_store_b128(bits, orsrc, lane_off, soff, 0);
             });
         }
+        if (CHAIN) {
+            if (mode == MODE_NEWVIEW) { X[0] = X[1]; X[1] = X[2]; X[2] = X[3]; X[3] = Y; }
+            else if (chL || chR) { const Operand t = X[0]; X[0] = X[1]; X[1] = X[2]; X[2] = X[3]; X[3] = t; }   // a tail leaves X as it was
+        }
         if (c + 1 < NCAT) {
-            if (PREFETCH) { if (lk == SK_CLV) curL = nxtL; if (rk == SK_CLV) curR = nxtR; }
-            else {
-                if (lk == SK_CLV) load_clv(curL, Lp, lane_off, rowbytes, c + 1);
-                if (rk == SK_CLV) load_clv(curR, Rp, lane_off, rowbytes, c + 1);
+            if (PREFETCH) { if (PF_L && lk == SK_CLV && !chL) curL = nxtL; if (rk == SK_CLV && !chR) curR = nxtR; }
+            if (!PF_L) { if (lk == SK_CLV && !chL) load_clv(curL, Lp, lane_off, rowbytes, c + 1); }
+            if (!PREFETCH) {
+                if (rk == SK_CLV && !chR) load_clv(curR, Rp, lane_off, rowbytes, c + 1);
             }
         }
     }
 
     ivec2 sc = {0, 0};
     if (q == 0) {
-        if (lk == SK_CLV) sc += *reinterpret_cast<const GLOBAL_AS ivec2 *>((gcptr)op.l_scl + 4 * p);
-        if (rk == SK_CLV) sc += *reinterpret_cast<const GLOBAL_AS ivec2 *>((gcptr)op.r_scl + 4 * p);
+        if (lk == SK_CLV) { if (chL) sc += xsc; else sc += *reinterpret_cast<const GLOBAL_AS ivec2 *>((gcptr)op.l_scl + 4 * p); }
+        if (rk == SK_CLV) { if (chR) sc += xsc; else sc += *reinterpret_cast<const GLOBAL_AS ivec2 *>((gcptr)op.r_scl + 4 * p); }
     }
     if (mode == MODE_NEWVIEW) {
         mx0 = fmax(mx0, __shfl_xor(mx0, 16)); mx0 = fmax(mx0, __shfl_xor(mx0, 32));
         mx1 = fmax(mx1, __shfl_xor(mx1, 16)); mx1 = fmax(mx1, __shfl_xor(mx1, 32));
         const bool n0 = mx0 < TWO_M256, n1 = mx1 < TWO_M256;
         if (__any(n0 || n1)) {               // rare: numerical rescue of underflowing patterns
-            if (n0 || n1) {
+            if (CHAIN) {
+                const double f0 = n0 ? TWO_P256 : 1.0, f1 = n1 ? TWO_P256 : 1.0;
+#pragma unroll
+                for (int c = 0; c < NCAT; ++c)
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) { X[c].v[k].x *= f0; X[c].v[k].y *= f1; }
+            }
+            if (keep && (n0 || n1)) {
 #pragma unroll 1
                 for (int r = 0; r < NCAT * 5; ++r) {
                     GLOBAL_AS dvec2 *ptr = reinterpret_cast<GLOBAL_AS dvec2 *>(O + (size_t)((r / 5) * NS + (r % 5) * 4) * rowbytes + lane_off);
@@ -388,7 +407,8 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
                 }
             }
         }
-        if (q == 0) { sc.x += n0 ? 1 : 0; sc.y += n1 ? 1 : 0; *reinterpret_cast<GLOBAL_AS ivec2 *>((gptr)op.out_scl + 4 * p) = sc; }
+        if (q == 0) { sc.x += n0 ? 1 : 0; sc.y += n1 ? 1 : 0; if (keep) *reinterpret_cast<GLOBAL_AS ivec2 *>((gptr)op.out_scl + 4 * p) = sc; }
+        if (CHAIN) xsc = sc;
     } else if (mode == MODE_SUMTABLE || mode == MODE_EVALUATE_CAT) {
         if (q == 0) *reinterpret_cast<GLOBAL_AS ivec2 *>((gptr)op.out_scl + 4 * p) = sc;
     } else {
@@ -419,16 +439,41 @@ __device__ __forceinline__ void stage_frags_dma(const NvOp &op, double *dst, int
     }
 }
 
+#ifndef PML_CHAIN_WAVES
+#define PML_CHAIN_WAVES 2
+#endif
+// left | right | inner (pitchfork) fragment sets of one op into the three consecutive LDS regions at dst
+__device__ __forceinline__ void stage_frags_dma3(const NvOp &op, double *dst, int lane, int wave) {
+    stage_frags_dma(op, dst, lane, wave);
+    const int lk = op.flags & 3, rk = (op.flags >> 2) & 3;
+    const double *inner = (lk == SK_PITCH) ? op.l.f : (rk == SK_PITCH) ? op.r.f : nullptr;
+    if (inner == nullptr) return;
+    for (int i = wave; i < 13; i += 4) {          // PFRAG doubles = 12.5 wave-instructions of 1 KiB
+        const int e = i * 128 + lane * 2;
+        if (e < PFRAG) __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(inner + e), (__attribute__((address_space(3))) void *)(dst + 2 * PFRAG + i * 128), 16, 0, 0);
+    }
+}
+
 template <int VARIANT>
 // VARIANT 5 = variant 1 compiled for 3 waves/SIMD (168 VGPRs, no spills)
-__global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : 3) void k_oplist(
+// VARIANT 9 = variant 1 with register chaining (kernels.h OPF_CHAIN_*): 80 more live VGPRs, 2 waves/SIMD
+// VARIANT 11 = 9 + double-buffered fragment staging by LDS-DMA, three regions per parity (2 workgroups per CU leave 80 KB each)
+__global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : (VARIANT >= 8) ? PML_CHAIN_WAVES : 3) void k_oplist(
         const NvOp *__restrict__ ops, const GeneRun *__restrict__ runs, int nruns, int blocks_per_gene, int any_pitch) {
     constexpr bool PREFETCH = !(VARIANT & 1);
-    constexpr bool DBUF = (VARIANT & 2) != 0 && VARIANT < 4;
+    constexpr bool CHAIN = VARIANT >= 8;                  // 8..11: bit 0 / bit 1 as above, three LDS regions per parity
+    constexpr bool DBUF3 = CHAIN && (VARIANT & 2) != 0;
+    constexpr bool DBUF = ((VARIANT & 2) != 0 && VARIANT < 4) || DBUF3;
+    constexpr int PARITY_STRIDE = (DBUF3 ? 3 : 2) * PFRAG;
+    Operand X[4]; ivec2 xsc = {0, 0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) X[c].v[k] = (dvec2){0.0, 0.0};
     // dynamic LDS: [left|right] fragments (x2 when double-buffered) [+ left-inner|right-inner fragments of
     // pitchfork sides when the launch has any] + the float tip-indicator table
     extern __shared__ double sP[];
-    const int nfrag_regions = (DBUF ? 4 : 2) + (any_pitch ? 1 : 0);
+    const int nfrag_regions = DBUF3 ? 6 : (DBUF ? 4 : 2) + (any_pitch ? 1 : 0);
     unsigned char *sT = reinterpret_cast<unsigned char *>(sP + nfrag_regions * PFRAG);
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share
     // an XCD and its L2), so all pattern blocks of one gene get the same blockIdx % 8: the gene's
@@ -445,15 +490,18 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : 3) void k_oplist(
     const bool active = (blk * 4 + wave) * PAT_PER_WAVE < mpad;
 
     for (int i = tid; i < TIPTAB; i += 256) sT[i] = (unsigned char)((code_mask(i / NS) >> (i % NS)) & 1u);
-    if (DBUF) stage_frags_dma(ops[run.op_begin], sP, lane, wave);
+    if (DBUF) { if (DBUF3) stage_frags_dma3(ops[run.op_begin], sP, lane, wave); else stage_frags_dma(ops[run.op_begin], sP, lane, wave); }
     __syncthreads();
     for (int oi = run.op_begin; oi < run.op_end; ++oi) {
         const NvOp &op = ops[oi];
         const double *buf = sP;
         if (DBUF) {
             const int par = (oi - run.op_begin) & 1;
-            buf = sP + par * 2 * PFRAG;
-            if (oi + 1 < run.op_end) stage_frags_dma(ops[oi + 1], sP + (par ^ 1) * 2 * PFRAG, lane, wave);
+            buf = sP + par * PARITY_STRIDE;
+            if (oi + 1 < run.op_end) {
+                if (DBUF3) stage_frags_dma3(ops[oi + 1], sP + (par ^ 1) * PARITY_STRIDE, lane, wave);
+                else stage_frags_dma(ops[oi + 1], sP + (par ^ 1) * PARITY_STRIDE, lane, wave);
+            }
         } else {
             if (oi > run.op_begin) __syncthreads();      // previous op: LDS reads and global stores complete
             const double2 *gl = reinterpret_cast<const double2 *>(op.pl);
@@ -473,7 +521,7 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : 3) void k_oplist(
             }
             __syncthreads();
         }
-        if (active) chunk_op<PREFETCH>(op, buf, sT, p, lane);
+        if (active) chunk_op<PREFETCH, CHAIN>(op, buf, sT, p, lane, X, xsc);
         if (op.aux != nullptr && blk == 0) for (int i = tid; i < NEWTON_SYNC_DOUBLES; i += 256) op.aux[i] = 0.0;   // arm k_newton's arrival counter
         if (DBUF) __syncthreads();           // next fragments landed (vmcnt(0) + barrier), stores done
     }
@@ -908,20 +956,34 @@ static int oplist_variant() {
     if (v < 0) { const char *e = getenv("PML_OPLIST_VARIANT"); v = e ? atoi(e) : 1; }
     return v;
 }
-void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, bool any_pitch, hipStream_t s) {
+void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, bool any_pitch, bool chained, hipStream_t s) {
     if (nruns <= 0) return;
     const int bpg = (max_mpad + PAT_PER_WG - 1) / PAT_PER_WG;
     const dim3 grid((unsigned)(((nruns + 7) / 8) * 8 * bpg)), block(256);
     int v = oplist_variant();
     if (any_pitch && (v == 2 || v == 3)) v = 1;          // pitchfork regions are not combined with double buffering
+    if (chained) {                                       // the descriptors carry OPF_CHAIN_* flags: only these variants honour them
+        static const int cv = std::getenv("PML_CHAIN_VARIANT") ? std::atoi(std::getenv("PML_CHAIN_VARIANT")) : 11;
+        v = (cv >= 8 && cv <= 11) ? cv : 11;
+    }
     const bool dbuf = (v == 2 || v == 3);
-    const size_t lds = (size_t)((dbuf ? 4 : 2) + (any_pitch ? 1 : 0)) * PFRAG * sizeof(double) + 512;   // 38.9 KB with pitchforks: 4 per CU
+    size_t lds = (size_t)((dbuf ? 4 : 2) + (any_pitch ? 1 : 0)) * PFRAG * sizeof(double) + 512;   // 38.9 KB with pitchforks: 4 per CU
+    if (v == 10 || v == 11) {
+        lds = (size_t)6 * PFRAG * sizeof(double) + 512;      // 77.3 KB: two workgroups per CU, which is what its 256 VGPRs allow anyway
+        static const hipError_t big11 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_oplist<11>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static const hipError_t big10 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_oplist<10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)big11; (void)big10;
+    }
     const int ap = any_pitch ? 1 : 0;
     switch (v) {
         case 0: hipLaunchKernelGGL(k_oplist<0>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
         case 2: hipLaunchKernelGGL(k_oplist<2>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
         case 3: hipLaunchKernelGGL(k_oplist<3>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
         case 5: hipLaunchKernelGGL(k_oplist<5>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
+        case 9: hipLaunchKernelGGL(k_oplist<9>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
+        case 8: hipLaunchKernelGGL(k_oplist<8>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
+        case 10: hipLaunchKernelGGL(k_oplist<10>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
+        case 11: hipLaunchKernelGGL(k_oplist<11>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
         default: hipLaunchKernelGGL(k_oplist<1>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
     }
 }
