@@ -279,6 +279,11 @@ __device__ __forceinline__ void load_pitch(Operand &o, const OpSide &sd, const d
     o.v[4] = (dvec2){v[4][0] * r0.c, v[4][1] * r1.c};
 }
 
+// the chained variants unroll the category loop (X[c] with a static index instead of rotating 80 registers per category:
+// C3 scoring launch 0.725 -> 0.693 ms, profiles/r02_ab_chain_unroll.txt); -DPML_CHAIN_UNROLL=0 is the A-B arm
+#ifndef PML_CHAIN_UNROLL
+#define PML_CHAIN_UNROLL 1
+#endif
 // One op on one chunk (32 patterns) of one wave.  All branches on op.* are wave-uniform.
 //   MODE_NEWVIEW : out[c][s] = (P_L,c . L_c)[s] * (P_R,c . R_c)[s], 2^256 rescue, scaling counts
 //   MODE_SUMTABLE: same contraction with the eigen-basis matrices (no rescue), counts = l + r
@@ -326,10 +331,14 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
     else if (lk == SK_CLV && !chL) load_clv(curL, Lp, lane_off, rowbytes, 0);      // evaluate: left side in output layout
     if (rk == SK_TIP) load_tip(curR, sT, cr, q);
     else if (rk == SK_CLV && !chR) load_clv(curR, Rp, lane_off, rowbytes, 0);
-#pragma unroll 1
+    constexpr int CAT_UNROLL = (CHAIN && PML_CHAIN_UNROLL) ? NCAT : 1;
+#pragma unroll CAT_UNROLL
     for (int c = 0; c < NCAT; ++c) {
         Operand Y;                                            // CHAIN: this category of the result
-        if (CHAIN) { if (chL) curL = X[0]; if (chR) curR = X[0]; }     // X is rotated once per category: X[0] is category c
+        if (CHAIN) {
+            if (CAT_UNROLL == NCAT) { if (chL) curL = X[c]; if (chR) curR = X[c]; }
+            else { if (chL) curL = X[0]; if (chR) curR = X[0]; }     // X is rotated once per category: X[0] is category c
+        }
         if (PREFETCH && c + 1 < NCAT) {                       // software prefetch of the next category
             if (PF_L && lk == SK_CLV && !chL) load_clv(nxtL, Lp, lane_off, rowbytes, c + 1);
             if (rk == SK_CLV && !chR) load_clv(nxtR, Rp, lane_off, rowbytes, c + 1);
@@ -367,7 +376,8 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
             });
         }
         if (CHAIN) {
-            if (mode == MODE_NEWVIEW) { X[0] = X[1]; X[1] = X[2]; X[2] = X[3]; X[3] = Y; }
+            if (CAT_UNROLL == NCAT) { if (mode == MODE_NEWVIEW) X[c] = Y; }
+            else if (mode == MODE_NEWVIEW) { X[0] = X[1]; X[1] = X[2]; X[2] = X[3]; X[3] = Y; }
             else if (chL || chR) { const Operand t = X[0]; X[0] = X[1]; X[1] = X[2]; X[2] = X[3]; X[3] = t; }   // a tail leaves X as it was
         }
         if (c + 1 < NCAT) {
@@ -964,15 +974,14 @@ void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad
     if (any_pitch && (v == 2 || v == 3)) v = 1;          // pitchfork regions are not combined with double buffering
     if (chained) {                                       // the descriptors carry OPF_CHAIN_* flags: only these variants honour them
         static const int cv = std::getenv("PML_CHAIN_VARIANT") ? std::atoi(std::getenv("PML_CHAIN_VARIANT")) : 11;
-        v = (cv >= 8 && cv <= 11) ? cv : 11;
+        v = cv == 9 ? 9 : 11;
     }
     const bool dbuf = (v == 2 || v == 3);
     size_t lds = (size_t)((dbuf ? 4 : 2) + (any_pitch ? 1 : 0)) * PFRAG * sizeof(double) + 512;   // 38.9 KB with pitchforks: 4 per CU
-    if (v == 10 || v == 11) {
+    if (v == 11) {
         lds = (size_t)6 * PFRAG * sizeof(double) + 512;      // 77.3 KB: two workgroups per CU, which is what its 256 VGPRs allow anyway
         static const hipError_t big11 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_oplist<11>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        static const hipError_t big10 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_oplist<10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)big11; (void)big10;
+        (void)big11;
     }
     const int ap = any_pitch ? 1 : 0;
     switch (v) {
@@ -981,8 +990,6 @@ void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad
         case 3: hipLaunchKernelGGL(k_oplist<3>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
         case 5: hipLaunchKernelGGL(k_oplist<5>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
         case 9: hipLaunchKernelGGL(k_oplist<9>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
-        case 8: hipLaunchKernelGGL(k_oplist<8>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
-        case 10: hipLaunchKernelGGL(k_oplist<10>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
         case 11: hipLaunchKernelGGL(k_oplist<11>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
         default: hipLaunchKernelGGL(k_oplist<1>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
     }
