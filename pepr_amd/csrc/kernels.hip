@@ -288,6 +288,9 @@ __device__ __forceinline__ void load_pitch(Operand &o, const OpSide &sd, const d
 //   MODE_NEWVIEW : out[c][s] = (P_L,c . L_c)[s] * (P_R,c . R_c)[s], 2^256 rescue, scaling counts
 //   MODE_SUMTABLE: same contraction with the eigen-basis matrices (no rescue), counts = l + r
 //   MODE_EVALUATE: per-pattern ln( 1/4 sum_c sum_s L_c[s] (pi P_c . R_c)[s] ) - counts*256 ln 2
+#ifndef PML_TIPLOOK
+#define PML_TIPLOOK 1
+#endif
 template <bool PREFETCH, bool CHAIN>
 __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restrict__ sP, const unsigned char *__restrict__ sT,
                                          int p, int lane, Operand (&X)[4], ivec2 &xsc) {
@@ -304,6 +307,7 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
     // register chaining (kernels.h OPF_CHAIN_*): X[0..3] = the four categories of the wave's last newview result, xsc its counts
     const bool chL = CHAIN && (op.flags & OPF_CHAIN_L) != 0, chR = CHAIN && (op.flags & OPF_CHAIN_R) != 0;
     const bool keep = !(CHAIN && (op.flags & OPF_NO_STORE) != 0);
+    constexpr bool TIPLOOK = PML_TIPLOOK != 0;
     constexpr bool PF_L = PREFETCH && !CHAIN;       // the chained variants prefetch the right side only (the chained child is the left one; registers)
     // (a plain tip side goes through the MFMA with its 0/1 indicator operand: the matrix pipe has slack and
     // table gathers for it measured slower)
@@ -326,10 +330,18 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
     if (rk >= SK_CHERRY) cr2 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)op.r.p1 + p);
     if (rk == SK_PITCH) cr3 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)op.r.p2 + p);
 
+    // A tip side with plain amino-acid codes needs no contraction: (P e_a)[s] = P[s][a] is an element of the fragment set
+    // already in LDS (A-fragment order: P[4 st + i][4 kk + k] at (st*5 + kk)*16 + k*4 + i) -- 5 LDS reads per pattern and
+    // category instead of 25 reads + 50 MFMAs, the same bits (the MFMA adds exact zeros).  Ambiguity codes and gaps (sums of
+    // columns) keep the MFMA path for the whole wave, so a pattern's bits do not depend on which path its wave took.
+    const bool lookL = TIPLOOK && mode < MODE_EVALUATE && lk == SK_TIP && !__any((cl & 0xFFu) >= 20u || (cl >> 8) >= 20u);
+    const bool lookR = TIPLOOK && mode < MODE_EVALUATE && rk == SK_TIP && !__any((cr & 0xFFu) >= 20u || (cr >> 8) >= 20u);
+    const double *tL0 = sP + ((cl & 0xFFu) >> 2) * 16 + (cl & 3u) * 4 + q, *tL1 = sP + ((cl >> 8) >> 2) * 16 + ((cl >> 8) & 3u) * 4 + q;
+    const double *tR0 = sP + PFRAG + ((cr & 0xFFu) >> 2) * 16 + (cr & 3u) * 4 + q, *tR1 = sP + PFRAG + ((cr >> 8) >> 2) * 16 + ((cr >> 8) & 3u) * 4 + q;
     Operand curL, curR, nxtL, nxtR;
-    if (lk == SK_TIP) load_tip(curL, sT, cl, q);
+    if (lk == SK_TIP && !lookL) load_tip(curL, sT, cl, q);
     else if (lk == SK_CLV && !chL) load_clv(curL, Lp, lane_off, rowbytes, 0);      // evaluate: left side in output layout
-    if (rk == SK_TIP) load_tip(curR, sT, cr, q);
+    if (rk == SK_TIP && !lookR) load_tip(curR, sT, cr, q);
     else if (rk == SK_CLV && !chR) load_clv(curR, Rp, lane_off, rowbytes, 0);
     constexpr int CAT_UNROLL = (CHAIN && PML_CHAIN_UNROLL) ? NCAT : 1;
 #pragma unroll CAT_UNROLL
@@ -360,8 +372,11 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
             }
         } else {
             double aL[5][2];
-            contract(aL, fL + c * 25 * 16, curL);
-            contract_stream(fR + c * 25 * 16, curR, [&](int st, double y0, double y1) {
+            if (lookL) {
+#pragma unroll
+                for (int st = 0; st < 5; ++st) { aL[st][0] = tL0[c * 400 + st * 80]; aL[st][1] = tL1[c * 400 + st * 80]; }
+            } else contract(aL, fL + c * 25 * 16, curL);
+            auto emit = [&](int st, double y0, double y1) {
                 const double o0 = aL[st][0] * y0, o1 = aL[st][1] * y1;
                 mx0 = fmax(mx0, o0); mx1 = fmax(mx1, o1);
                 if (CHAIN) Y.v[st] = (dvec2){o0, o1};
@@ -373,7 +388,11 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
                 const int soff = (c * NS + st * 4) * (int)rowbytes;
                 if (nt_store) __builtin_amdgcn_raw_buffer_store_b128(bits, orsrc, lane_off, soff, 2);      // aux 2 = nt
                 else __builtin_amdgcn_raw_buffer_store_b128(bits, orsrc, lane_off, soff, 0);
-            });
+            };
+            if (lookR) {
+#pragma unroll
+                for (int st = 0; st < 5; ++st) emit(st, tR0[c * 400 + st * 80], tR1[c * 400 + st * 80]);
+            } else contract_stream(fR + c * 25 * 16, curR, emit);
         }
         if (CHAIN) {
             if (CAT_UNROLL == NCAT) { if (mode == MODE_NEWVIEW) X[c] = Y; }
