@@ -660,7 +660,7 @@ template <bool REG, int ROLE>
 __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, const NewtonReq &r, NewtonShared &sh,
                                             int S, int wg, int p_begin, int p_end) {
     constexpr bool SVC = ROLE != 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mpad = r.mpad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u64 *gran = reinterpret_cast<u64 *>(r.sync);       // [parity 2][slice NEWTON_MAX_SPLIT][6] granules, zeroed by the sumtable op
     int nevals = 0;
     bool failed = false;
