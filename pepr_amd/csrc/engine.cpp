@@ -13,7 +13,6 @@
 #include <chrono>
 #include <cmath>
 #include <thread>
-#include <unordered_map>
 #include <cstring>
 
 namespace pml {
@@ -660,23 +659,36 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     // one transition-matrix request (fragment set or tip table) for branch (v, slot q) of gene g
     // one request per (gene, kind, tree branch) and launch; never while a plan is being recorded (a replay refreshes
     // each request from ITS branch)
-    std::unordered_map<uint64_t, const double *> shared;
+    // keyed requests live in a flat table stamped with the launch number (no hashing, nothing to clear): one entry per
+    // (gene, kind, directed branch slot); the undirected branch is the smaller of its two slots
+    bool req_ok = req_off.size() == genes.size() + 1;
+    for (size_t g = 0; req_ok && g < genes.size(); ++g) req_ok = req_off[g + 1] - req_off[g] == (size_t)9 * genes[g].tree.nnodes();
+    if (!req_ok) {
+        req_off.assign(genes.size() + 1, 0);
+        for (size_t g = 0; g < genes.size(); ++g) req_off[g + 1] = req_off[g] + (size_t)3 * 3 * genes[g].tree.nnodes();
+        req_stamp.assign(req_off.back(), 0); req_ptr.assign(req_off.back(), nullptr); req_launch = 0;
+        val_bucket.assign(genes.size() * 3, {}); val_stamp.assign(genes.size() * 3, 0);
+    }
+    if (++req_launch == 0) {                    // the 32-bit launch number wrapped: no stale stamp may match it
+        std::fill(req_stamp.begin(), req_stamp.end(), 0u); std::fill(val_stamp.begin(), val_stamp.end(), 0u); req_launch = 1;
+    }
     // requests whose length belongs to no branch of the tree (SPR: joined / halved branches) are shared by VALUE: the
     // same (gene, kind, length) gives the same matrices: one list of (length bits, matrices) per (gene, kind).
-    std::unordered_map<uint64_t, std::vector<std::pair<uint64_t, const double *>>> shared_val;
     bool req_overflow = false;
     auto add_req = [&](size_t g, double t, int kind, int v, int q) -> const double * {
-        uint64_t key = 0, tbits = 0;
+        uint64_t tbits = 0; size_t key = 0;
         std::vector<std::pair<uint64_t, const double *>> *bucket = nullptr;
         if (!record_plan) {
             if (v >= 0) {
-                const int w = genes[g].tree.nbr[v][q], a = v * 3 + q, b = w * 3 + genes[g].tree.slot(w, v);
-                key = ((uint64_t)g << 34) | ((uint64_t)kind << 32) | (uint64_t)(uint32_t)std::min(a, b);
-                auto it = shared.find(key);
-                if (it != shared.end()) return it->second;
+                const Tree &T = genes[g].tree;
+                const int w = T.nbr[v][q], a = v * 3 + q, b = w * 3 + T.slot(w, v);
+                key = req_off[g] + (size_t)kind * 3 * T.nnodes() + (size_t)std::min(a, b);
+                if (req_stamp[key] == req_launch) return req_ptr[key];
             } else {
                 std::memcpy(&tbits, &t, 8);
-                bucket = &shared_val[((uint64_t)g << 2) | (uint64_t)kind];          // exact (gene, kind); a few hundred lengths at most
+                const size_t bi = g * 3 + (size_t)kind;                              // exact (gene, kind); a few hundred lengths at most
+                if (val_stamp[bi] != req_launch) { val_bucket[bi].clear(); val_stamp[bi] = req_launch; }
+                bucket = &val_bucket[bi];
                 for (auto &e : *bucket) if (e.first == tbits) return e.second;
             }
         }
@@ -686,7 +698,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         r.tp = (chain && v >= 0 && genes[g].len_pending[(size_t)v * 3 + q]) ? genes[g].d_len + (size_t)v * 3 + q : nullptr;
         last_src.push_back({(int)g, v, q, kind});
         const double *out = frags_buf + (ireq++) * FRAG_STRIDE;
-        if (!record_plan) { if (v >= 0) shared.emplace(key, out); else bucket->push_back({tbits, out}); }
+        if (!record_plan) { if (v >= 0) { req_stamp[key] = req_launch; req_ptr[key] = out; } else bucket->push_back({tbits, out}); }
         return out;
     };
     // resolves one side of an op: pointers, kind, scaling counts; `want_table`: newview tip sides look
@@ -735,7 +747,9 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     };
 
     // tails by gene, in submission order (<= MAXTAIL per gene per run)
-    std::vector<std::vector<int>> tails_of(ngenes);
+    std::vector<std::vector<int>> &tails_of = run_tails_of;          // kept between launches: no allocations per launch
+    if (tails_of.size() != ngenes) tails_of.assign(ngenes, {});
+    for (auto &v : tails_of) v.clear();
     for (size_t i = 0; i < ntail; ++i) {
         if (tails[i].slot < 0 || tails[i].slot >= MAXTAIL) return ctx->fail(-1, "internal: bad tail slot");
         tails_of[tails[i].gene].push_back((int)i);
