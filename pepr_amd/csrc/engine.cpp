@@ -513,9 +513,15 @@ int Batch::need(int g, int v, int to, std::vector<PendingOp> &ops) {
     Gene &G = genes[g];
     const int nt = G.aln.ntax;
     if (v < nt || virt_kind(g, v, to)) return 0;
+    {                                                   // most calls ask for a message that is valid or already pending
+        const int idx0 = (v - nt) * 3 + G.tree.slot(v, to);
+        if (G.valid[idx0]) return 0;
+        if (G.pend_level[idx0] >= 0) return G.pend_level[idx0];
+    }
     // explicit stack (trees can be caterpillars of depth ~ntax)
     struct Frame { int v, to, k, stage, lv[2]; };
     std::vector<Frame> st;
+    st.reserve(64);
     st.push_back({v, to, G.tree.slot(v, to), 0, {0, 0}});
     int ret = 0;
     while (!st.empty()) {
