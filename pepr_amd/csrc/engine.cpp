@@ -783,7 +783,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         };
         auto consume_last = [&]() {                     // the last newview's result is taken from the registers by the operation being built
             any_chain = true;
-            if (chain_nostore) { hops[last_nv].flags |= OPF_NO_STORE; ops[last_nv_op].unstored = true; }
+            if (chain_nostore || ops[last_nv_op].transient) { hops[last_nv].flags |= OPF_NO_STORE; ops[last_nv_op].unstored = true; }
         };
         auto emit_tail = [&](const Tail &t) -> int {
             NvOp &d = hops[nout++];

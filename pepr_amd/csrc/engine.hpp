@@ -93,7 +93,8 @@ struct Side { int kind, id; };
 // bv/bq (optional, scratch outputs): the tree branch (node, slot) child c's length belongs to -- lets run() share ONE
 // transition-matrix request among all operations of a launch that cross the same branch
 struct PendingOp { int gene, out_kind, out_id, level; Side child[2]; double t[2]; int bv[2] = {-1, -1}, bq[2] = {0, 0};
-                   bool unstored = false; /* run(): the result stayed in registers (OPF_NO_STORE) and is not valid in memory */ };
+                   bool unstored = false; /* run(): the result stayed in registers (OPF_NO_STORE) and is not valid in memory */
+                   bool transient = false; /* caller: only the operation or tail that directly follows reads the result (scratch slots) */ };
 
 struct Batch {
     Ctx *ctx = nullptr;

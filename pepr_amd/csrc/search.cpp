@@ -483,6 +483,7 @@ int Batch::spr_round(const std::vector<char> &active, int radius, std::vector<do
                         }
                         const double tgh = T.len[u.g][T.slot(u.g, u.h)];
                         PendingOp I; I.gene = g; I.out_kind = SIDE_SCRATCH; I.out_id = SPR_INS_SLOT; I.level = 0;
+                        I.transient = true;                        // read by the evaluation right behind it and by nothing else
                         I.child[0] = {SIDE_SCRATCH, u.mslot}; I.t[0] = 0.5 * tgh; I.child[1] = msg(g, u.h, u.g); I.t[1] = 0.5 * tgh;
                         ops.push_back(I); ++count;
                         Tail t{g, sp, {SIDE_SCRATCH, SPR_INS_SLOT}, MODE_EVALUATE, P.ts, 0, 0, count};
