@@ -1056,19 +1056,23 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
     const int n = (int)genes.size();
     maxdelta.assign(n, 0.0);
     // per-gene DFS edge order, restricted to dirty branches
-    std::vector<std::vector<std::pair<int, int>>> order(n);
-    std::vector<std::vector<uint8_t>> next(n);
+    // (scratch kept between passes: this set-up runs while the device is idle)
+    std::vector<std::vector<std::pair<int, int>>> &order = pass_order;
+    std::vector<std::vector<uint8_t>> &next = pass_next;
+    if ((int)order.size() != n) { order.assign(n, {}); next.assign(n, {}); }
     size_t maxlen = 0;
+    struct F { int v, from, k; };
+    std::vector<F> st; st.reserve(256);
     for (int g = 0; g < n; ++g) {
-        if (!active[g]) continue;
+        order[g].clear();
+        if (!active[g]) { next[g].clear(); continue; }
         Gene &G = genes[g];
         const Tree &T = G.tree; const int nt = T.ntax;
         if (G.dirty.size() != (size_t)T.nnodes() * 3) G.mark_all();
         next[g].assign((size_t)T.nnodes() * 3, 0);
         // emulate the recursion: visit(v, from): for k: edge (v,w); if inner recurse
         // (edge list fixed up-front: topology does not change during a pass)
-        struct F { int v, from, k; };
-        std::vector<F> st{{0, -1, 0}};
+        st.clear(); st.push_back({0, -1, 0});
         while (!st.empty()) {
             F &f = st.back();
             if (f.k >= 3) { st.pop_back(); continue; }

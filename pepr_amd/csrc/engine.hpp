@@ -133,6 +133,7 @@ struct Batch {
     std::vector<ReqSrc> last_src;
     std::vector<size_t> req_off; std::vector<uint32_t> req_stamp; std::vector<const double *> req_ptr; uint32_t req_launch = 0;   // run(): keyed request table
     std::vector<std::vector<int>> run_tails_of;
+    std::vector<std::vector<std::pair<int, int>>> pass_order; std::vector<std::vector<uint8_t>> pass_next;      // smooth_pass scratch
     std::vector<std::vector<std::pair<uint64_t, const double *>>> val_bucket; std::vector<uint32_t> val_stamp;   // run(): requests shared by value
     // chained mode: run() enqueues its copy + kernels and returns WITHOUT synchronising; descriptors are bump-
     // allocated in the staging buffer; branch lengths optimised earlier in the chain are read from Gene::d_len
