@@ -917,6 +917,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         HIPCHK(hipGetLastError());
         const double t_done = now_ms();
         ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += t_done - t_launched;
+        host_phase_ms[HP_RUN_SYNCED] += t_launched - t_begin;           // descriptor build of a launch the device waited for
         ctx->resolve_events();
         // a Newton request whose cross-workgroup exchange timed out reports lnL = NaN (k_newton): that is a device
         // failure, never a result
@@ -1055,6 +1056,7 @@ int Batch::root_derivs(double *lnl, double *d1, double *d2) {
 int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &maxdelta, double thr) {
     const int n = (int)genes.size();
     maxdelta.assign(n, 0.0);
+    double hp_t = now_ms();
     // per-gene DFS edge order, restricted to dirty branches
     // (scratch kept between passes: this set-up runs while the device is idle)
     std::vector<std::vector<std::pair<int, int>>> &order = pass_order;
@@ -1084,6 +1086,7 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
         maxlen = std::max(maxlen, order[g].size());
     }
     ++cnt_passes;
+    host_phase_ms[HP_PASS_SETUP] += now_ms() - hp_t; hp_t = now_ms();
     // The whole pass is enqueued without a host round trip: a branch optimised at step i has its new length in
     // Gene::d_len (written by k_newton), and every later transition-matrix request across that branch reads it from
     // there (PmatReq::tp).  The host learns the new lengths after ONE synchronisation at the end of the pass.
@@ -1154,10 +1157,12 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
             }
         }
     }
+    host_phase_ms[HP_PASS_STEPS] += now_ms() - hp_t;
     if (chain) {
         const double t0 = now_ms();
         if (int rc = chain_sync()) { chain = false; return rc; }
         ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += now_ms() - t0;
+        host_phase_ms[HP_PASS_SYNC] += now_ms() - t0; hp_t = now_ms();
         chain = false; lanes_active = false;
         for (auto &d : done) if (!std::isfinite(h_chain[4 * d.idx + 1]))
             return ctx->fail(-5, "k_newton: cross-workgroup exchange timed out (non-finite result)");
@@ -1172,6 +1177,7 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
         for (auto &G : genes) std::fill(G.len_pending.begin(), G.len_pending.end(), 0);
     }
     for (int g = 0; g < n; ++g) if (active[g]) genes[g].dirty.swap(next[g]);
+    host_phase_ms[HP_PASS_POST] += now_ms() - hp_t;
     return 0;
 }
 
@@ -1275,6 +1281,7 @@ int Batch::opt_alpha(const std::vector<char> &active, double *lnl, double tol) {
     for (int g = 0; g < n; ++g) if (act[g]) open_window(g, std::log(genes[g].alpha), -f[g]);
     for (;;) {
         bool any = false;
+        const double hp_a = now_ms();
         for (int g = 0; g < n; ++g) {
             if (!act[g]) continue;
             for (;;) {
@@ -1284,6 +1291,7 @@ int Batch::opt_alpha(const std::vector<char> &active, double *lnl, double tol) {
                 act[g] = 0; break;
             }
         }
+        host_phase_ms[HP_ALPHA_HOST] += now_ms() - hp_a;
         if (!any) break;
         if (int rc = score(act, f.data())) return rc;
         for (int g = 0; g < n; ++g) if (act[g]) br[g].update(-f[g]);

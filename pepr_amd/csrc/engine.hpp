@@ -126,6 +126,9 @@ struct Batch {
         std::vector<unsigned> rates_seen;          // per gene: rates_epoch the descriptors carry
     } plan;
     long cnt_smooth = 0, cnt_nni = 0, cnt_spr = 0, cnt_eval = 0, cnt_passes = 0;   // run() calls by purpose (PML_TRACE)
+    // host wall time by phase, ms (PML_TRACE prints them at the end of a search): where the device waits for the host
+    enum { HP_PASS_SETUP, HP_PASS_STEPS, HP_PASS_SYNC, HP_PASS_POST, HP_NNI_BUILD, HP_NNI_RUN, HP_NNI_SELECT, HP_ALPHA_HOST, HP_RUN_SYNCED, HP_N };
+    double host_phase_ms[HP_N] = {0};
     unsigned topo_epoch = 0;       // bumped whenever a search may change a topology
     bool score_only_batch = false;
     int replay_plan(double *lnl);

@@ -1,3 +1,4 @@
+#include <chrono>
 // search.cpp -- topology search driver (NNI hill climbing) on top of the batch engine.
 //
 // Replaces the tree search inside the external programs PEPR spawns (FastTree's ML-NNI rounds,
@@ -25,6 +26,7 @@
          if (e_ != hipSuccess) return ctx->fail(-4, std::string("HIP: ") + hipGetErrorString(e_)); } while (0)
 
 namespace pml {
+static double hp_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 namespace {
 constexpr double NNI_MIN_GAIN = 0.01;
@@ -159,6 +161,7 @@ int Batch::nni_round(const std::vector<char> &active, std::vector<double> &lnl, 
     const int n = (int)genes.size();
     ++topo_epoch;
     applied.assign(n, 0);
+    double hp_t = hp_now();
     // per-gene edge lists in oracle order
     std::vector<std::vector<std::pair<int, int>>> edges(n);
     size_t maxsteps = 0;
@@ -242,7 +245,9 @@ int Batch::nni_round(const std::vector<char> &active, std::vector<double> &lnl, 
                 }
             }
         }
+        host_phase_ms[HP_NNI_BUILD] += hp_now() - hp_t; hp_t = hp_now();
         if (int rc = run(ops, tails)) return rc;
+        host_phase_ms[HP_NNI_RUN] += hp_now() - hp_t; hp_t = hp_now();
         for (int g = 0; g < n; ++g) {
             if (!active[g] || e0 >= edges[g].size()) continue;
             size_t k = rbase[g];
@@ -296,6 +301,7 @@ int Batch::nni_round(const std::vector<char> &active, std::vector<double> &lnl, 
         }
         invalidate_all(g); stageA[g] = 1;
     }
+    host_phase_ms[HP_NNI_SELECT] += hp_now() - hp_t;
     std::vector<double> l1(n, 0.0);
     bool any = false; for (char a : stageA) any |= a;
     if (!any) return 0;
@@ -614,6 +620,9 @@ int Batch::search(bool nni, int spr_radius, bool opt_alpha_flag, double eps, dou
     newton_tol = 1e-8;
     if (int rc = optimize(opt_alpha_flag, eps, lnl.data())) return rc;
     if (trace) fprintf(stderr, "[pml] search done: passes %ld smooth-steps %ld nni-steps %ld spr-steps %ld evals %ld\n", cnt_passes, cnt_smooth, cnt_nni, cnt_spr, cnt_eval);
+    if (trace) fprintf(stderr, "[pml] host ms: pass set-up %.1f, pass steps (overlapped) %.1f, pass sync wait %.1f, pass post %.1f, nni build %.1f, nni run %.1f, nni select %.1f, alpha host %.1f, builds of synchronised launches %.1f\n",
+                       host_phase_ms[HP_PASS_SETUP], host_phase_ms[HP_PASS_STEPS], host_phase_ms[HP_PASS_SYNC], host_phase_ms[HP_PASS_POST], host_phase_ms[HP_NNI_BUILD],
+                       host_phase_ms[HP_NNI_RUN], host_phase_ms[HP_NNI_SELECT], host_phase_ms[HP_ALPHA_HOST], host_phase_ms[HP_RUN_SYNCED]);
     for (int g = 0; g < n; ++g) lnl_out[g] = lnl[g];
     for (int g = 0; g < n; ++g) if (!tree_displays(genes[g].tree, genes[g].cons)) return ctx->fail(-5, "internal: result violates the topological constraints");
     return 0;
