@@ -110,41 +110,47 @@ __global__ __launch_bounds__(PMAT_THREADS, 2) void k_pmat(const ModelDev *__rest
         for (int kk = 0; kk < 5; ++kk) ek[kk] = sEw[cb * NS + 4 * kk + k4];
         __builtin_amdgcn_wave_barrier();                       // every lane has its five values before the row is rewritten
         double *out = frags + (size_t)rq * FRAG_STRIDE;
-        double rowsum[5];                                      // tip table, code "any state": sum over the lane's columns
+        double T[5][5];                                        // [st][nt]: the lane's element of tile (st, nt) in its block's category
 #pragma unroll
         for (int st = 0; st < 5; ++st) {
             double a[5];
 #pragma unroll
             for (int kk = 0; kk < 5; ++kk) a[kk] = Au[st][kk] * ek[kk];
-            double acc[5];
 #pragma unroll
             for (int nt = 0; nt < 5; ++nt) {
                 double d = 0.0;
 #pragma unroll
                 for (int kk = 0; kk < 5; ++kk) d = mfma4(a[kk], Bu[kk][nt], d);
-                acc[nt] = d < 0.0 ? 0.0 : d;
+                T[st][nt] = d < 0.0 ? 0.0 : d;
             }
-            if (kind != PM_TIPTABLE) {
+        }
+        if (kind != PM_TIPTABLE) {
+#pragma unroll
+            for (int st = 0; st < 5; ++st) {
                 const double scale = kind == PM_FRAGS_PI ? pi_row[st] : 1.0;
 #pragma unroll
                 for (int nt = 0; nt < 5; ++nt)                 // fragment (c, st, kk = nt), element 4 * (column in tile) + (row in tile)
-                    out[((cb * 25 + st * 5 + nt) << 4) + (i4 << 2) + k4] = acc[nt] * scale;
-            } else {
-                // T[c][code][q = row in tile][kk = st]; plain states: the lane's own element of column 4 nt + (lane&3)
-#pragma unroll
-                for (int nt = 0; nt < 5; ++nt)
-                    out[((cb * NCODES + 4 * nt + i4) * 4 + k4) * TIPTAB_KK + st] = acc[nt];
-                const double b01 = acc[0] + quad_swap<0xB1>(acc[0]);       // columns {0,1} / {2,3} of tile 0 pairwise
-                if (i4 == 2) out[((cb * NCODES + 20) * 4 + k4) * TIPTAB_KK + st] = b01;                  // B = N | D (columns 2, 3)
-                const double z12 = acc[1] + quad_swap<0xD8>(acc[1]);       // quad_perm [0,2,1,3]: lanes 1 and 2 exchange
-                if (i4 == 1) out[((cb * NCODES + 21) * 4 + k4) * TIPTAB_KK + st] = z12;                  // Z = Q | E (columns 5, 6)
-                rowsum[st] = quad_sum(acc[0] + acc[1] + acc[2] + acc[3] + acc[4]);
-                if (i4 == 0) out[((cb * NCODES + 22) * 4 + k4) * TIPTAB_KK + st] = rowsum[st];           // gap / unknown: every state
+                    out[((cb * 25 + st * 5 + nt) << 4) + (i4 << 2) + k4] = T[st][nt] * scale;
             }
-        }
-        if (kind == PM_TIPTABLE && i4 < 3) {                   // the padding slot kk = 5 of every record
-#pragma unroll 1
-            for (int code = i4; code < NCODES; code += 3) out[((cb * NCODES + code) * 4 + k4) * TIPTAB_KK + 5] = 0.0;
+        } else {
+            // T[c][code][q = row in tile][kk = st]: a record is 6 doubles (5 + padding) = three 16-byte stores of one lane
+            auto put = [&](int code, double v0, double v1, double v2, double v3, double v4) {
+                typedef double dv2 __attribute__((ext_vector_type(2)));
+                dv2 *rec = reinterpret_cast<dv2 *>(out + ((cb * NCODES + code) * 4 + k4) * TIPTAB_KK);
+                rec[0] = (dv2){v0, v1}; rec[1] = (dv2){v2, v3}; rec[2] = (dv2){v4, 0.0};
+            };
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) put(4 * nt + i4, T[0][nt], T[1][nt], T[2][nt], T[3][nt], T[4][nt]);   // plain states: column 4 nt + (lane&3)
+            double bz[5], zq[5], any[5];
+#pragma unroll
+            for (int st = 0; st < 5; ++st) {
+                bz[st] = T[st][0] + quad_swap<0xB1>(T[st][0]);             // columns {0,1} / {2,3} of tile 0 pairwise
+                zq[st] = T[st][1] + quad_swap<0xD8>(T[st][1]);             // quad_perm [0,2,1,3]: lanes 1 and 2 exchange
+                any[st] = quad_sum(T[st][0] + T[st][1] + T[st][2] + T[st][3] + T[st][4]);
+            }
+            if (i4 == 2) put(20, bz[0], bz[1], bz[2], bz[3], bz[4]);       // B = N | D (columns 2, 3)
+            if (i4 == 1) put(21, zq[0], zq[1], zq[2], zq[3], zq[4]);       // Z = Q | E (columns 5, 6)
+            if (i4 == 0) put(22, any[0], any[1], any[2], any[3], any[4]);  // gap / unknown: every state
         }
     }
 }
