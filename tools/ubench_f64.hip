@@ -20,6 +20,16 @@ __global__ __launch_bounds__(256) void k(double *out, int iters) {
             s1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, s1, 0, 0, 0);
             s2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, s2, 0, 0, 0);
             s3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, s3, 0, 0, 0);
+        } else if (KIND == 3) {          // ONE dependent chain (4 instructions per iteration, each waits for the last)
+            s0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, s0, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, s0, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, s0, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, s0, 0, 0, 0);
+        } else if (KIND == 4) {          // TWO chains interleaved (k_oplist's streamed second-side contraction)
+            s0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, s1, 0, 0, 0);
         } else {
             s0 = __builtin_fma(a, b, s0); s1 = __builtin_fma(a, b, s1);
             s2 = __builtin_fma(a, b, s2); s3 = __builtin_fma(a, b, s3);
@@ -56,6 +66,8 @@ int main() {
         run<0>("mfma_f64_16x16x4", 2048, w);
         run<1>("mfma_f64_4x4x4_4b", 512, w);
         run<2>("v_fma_f64", 128, w);
+        run<3>("mfma_4x4x4 1 chain", 512, w);
+        run<4>("mfma_4x4x4 2 chains", 512, w);
     }
     size_t n = (size_t)1 << 27;   // 2 GiB each
     double2 *a, *b; hipMalloc(&a, n * 16); hipMalloc(&b, n * 16); hipMemset(a, 1, n * 16);
