@@ -925,7 +925,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             if (t.mode == MODE_EVALUATE_CAT) continue;
             const double *h = t.result_host ? t.result_host : (t.result_dev ? nullptr : res(t.gene, t.slot));
             if (h && !std::isfinite(t.mode == MODE_EVALUATE ? h[0] : h[1]))
-                return ctx->fail(-5, t.mode == MODE_EVALUATE ? "device returned a non-finite likelihood" : "k_newton: cross-workgroup exchange timed out (non-finite result)");
+                return ctx->fail(-5, t.mode == MODE_EVALUATE ? "device returned a non-finite likelihood" : "k_newton: cross-workgroup exchange timed out (non-finite result); is another process using this GPU? the engine needs the device to itself");
         }
     }
     for (auto &o : ops) if (o.out_kind == SIDE_MSG) { Gene &G = genes[o.gene]; G.valid[o.out_id] = o.unstored ? 0 : 1; G.pend_level[o.out_id] = -1; }
@@ -1165,7 +1165,7 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
         host_phase_ms[HP_PASS_SYNC] += now_ms() - t0; hp_t = now_ms();
         chain = false; lanes_active = false;
         for (auto &d : done) if (!std::isfinite(h_chain[4 * d.idx + 1]))
-            return ctx->fail(-5, "k_newton: cross-workgroup exchange timed out (non-finite result)");
+            return ctx->fail(-5, "k_newton: cross-workgroup exchange timed out (non-finite result); is another process using this GPU? the engine needs the device to itself");
         for (auto &d : done) {
             Gene &G = genes[d.gene];
             const double nl = h_chain[4 * d.idx], dl = std::fabs(nl - d.old);
