@@ -17,15 +17,27 @@ summed over all ranks.  Launch: python bench.py --gpus N --steps K --warmup W.  
 WORLD_SIZE in the environment this process only SPAWNS the N ranks (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*
 set) before anything touches the GPU and exits with their code; under torch.distributed.run the ranks come from the
 environment and --gpus must equal WORLD_SIZE.
+
+Beside `value` the line carries
+  stored_traversal   the same pass with every CLV written to HBM (what a search runs; second timed leg),
+  cold               the K steps timed right after the W warm-up steps, before the extra clock warm-up,
+  search / search_raxml_path   complete tree inferences per second (the other half of BASELINE.json's metric),
+  c4_shard (N = 1) / c4_strong (N > 1)   BASELINE config[3]: this GPU's 63-gene share, resp. the 500-gene job dealt by cost
+                     over the N ranks with the one gather of result records (BENCH_NO_C4=1 skips it).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+PEAK_F64_MATRIX_TFLOPS = 78.6      # vendor FP64 matrix figure SURVEY 8d uses (v_mfma_f64_4x4x4 measured 62-67 on the box, profiles/r01_ubench_f64.txt)
+PEAK_HBM_GBS = 8000.0
+SHAPES = {"c3": (50, 1000, 128), "c4": (200, 5000, 63), "tiny": (12, 200, 8)}
 
 
 def _cpu_worker(args):
@@ -52,6 +64,22 @@ def _cpu_search_worker(args):
     t0 = _t.time()
     e.search(None, 0, 1e-3)
     return _t.time() - t0
+
+
+def _sim_worker(args):
+    from pepr_amd import synth
+    return synth.simulate_alignment(*args)
+
+
+def simulate(ntax, nsites, gene_ids, alpha):
+    """seeded synthetic genes (seed = 1 + global gene id); large ones on host worker processes that never touch the GPU"""
+    from pepr_amd import synth
+    jobs = [(ntax, nsites, 1 + gid, alpha) for gid in gene_ids]
+    if ntax * nsites * len(jobs) < 20_000_000 or (os.cpu_count() or 1) < 4:
+        return [synth.simulate_alignment(*j) for j in jobs]
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(max(1, min(len(jobs), 16, os.cpu_count() or 1))) as pool:
+        return pool.map(_sim_worker, jobs, chunksize=1)
 
 
 def cpu_baseline(genes, alpha, budget_s=12.0):
@@ -98,7 +126,6 @@ def launch_ranks(ngpus):
     """Parent of `python bench.py --gpus N` (N > 1, no WORLD_SIZE): starts one child per GPU with the torch.distributed
     environment and waits.  It never imports torch or touches the GPU, and nothing is exec'ed from a GPU process."""
     import socket
-    import subprocess
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
     for r in range(ngpus):
@@ -140,6 +167,61 @@ def plumbing_only(world_expected):
     return 0
 
 
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:       # noqa: BLE001 -- no git on the GPU box's copy (.git does not travel)
+        return None
+
+
+def committed_pmc(workload):
+    """HBM bytes per k_oplist launch and matrix-pipe busy share from the COMMITTED rocprofv3 --pmc passes of this same command
+    (separate passes per counter group, tools/pmc_collect.sh; counters cannot be read from inside the run).  Every file
+    carries the commit it was measured at, which is handed through so that a stale file is visible in the line."""
+    out = {"traffic": None, "traffic_source": None, "traffic_commit": None, "pipe_busy": None, "pipe_busy_source": None}
+    for rnd in ("r03", "r02"):
+        pmc = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (rnd, workload))
+        if out["traffic"] is None and os.path.exists(pmc):
+            d = json.load(open(pmc))
+            out["traffic"] = d["traffic_bytes_per_launch"]
+            out["traffic_source"] = "committed PMC passes, profiles/" + os.path.basename(pmc)
+            out["traffic_commit"] = d.get("commit", "not stamped (before round 3)")
+        pb = os.path.join(ROOT, "profiles", "%s_pmc_k_oplist_chained_%s.json" % (rnd, workload))
+        if out["pipe_busy"] is None and os.path.exists(pb):
+            d = json.load(open(pb))
+            out["pipe_busy"] = d["derived"]["mfma_pipe_busy_frac"]
+            out["pipe_busy_source"] = "profiles/%s @ %s" % (os.path.basename(pb), d.get("commit", "not stamped (before round 3)"))
+    return out
+
+
+def roofline_of(nv, pmc, upper_bound_flops, stored=False):
+    """roofline object for the k_oplist launches counted in the kernel statistics `nv` (HIP events on the engine's stream).
+    achieved = SURVEY 8d's PER-OPERATION flops of a launch (inner-inner 6480, tip-inner 3280, tip-tip 80, evaluate 3360 per
+    pattern: pml_kernel_flops) / the average launch time; peak = the f64 matrix figure.  SURVEY 8d's closed form
+    6480 (n-2) + 3360 ('upper bound ignoring tip savings') is printed beside it under its own name, never as `frac`."""
+    n = max(nv["launches"], 1)
+    avg_ms = nv["ms"] / n
+    sec = avg_ms * 1e-3
+    flops = nv["algo_flops"] / n
+    algo_bytes = nv["algo_bytes"] / n
+    ach = flops / sec / 1e12 if sec > 0 else 0.0
+    r = {"bound": "mfma", "kernel": "k_oplist (newview + evaluate)", "achieved": ach, "peak": PEAK_F64_MATRIX_TFLOPS, "unit": "TFLOP/s",
+         "frac": ach / PEAK_F64_MATRIX_TFLOPS, "avg_launch_ms": avg_ms, "algo_flops_per_launch": flops,
+         "traffic": None if stored else pmc["traffic"], "traffic_source": None if stored else pmc["traffic_source"],
+         "traffic_commit": None if stored else pmc["traffic_commit"],
+         "matrix_pipe_busy_frac_pmc": None if stored else pmc["pipe_busy"], "matrix_pipe_busy_source": None if stored else pmc["pipe_busy_source"],
+         "survey_8d_closed_form": {"flops_per_launch": upper_bound_flops, "note": "6480 (n-2) + 3360 flop per site-lnL, 8d's upper bound ignoring tip savings; NOT what the kernel executes",
+                                   "tflops": upper_bound_flops / sec / 1e12 if sec > 0 else 0.0},
+         # the HBM side: 8d's per-operation bytes of the op list (what an unfused traversal would move) next to what the
+         # counters saw; register chaining keeps a child its parent consumes next in VGPRs, so the first can exceed the
+         # chip's 8 TB/s -- it is an accounting figure, not a transfer rate, and carries no `frac`
+         "hbm": {"algorithmic_bytes_per_launch": algo_bytes, "algorithmic_GB_per_s": algo_bytes / sec / 1e9 if sec > 0 else 0.0,
+                 "peak_GB_per_s": PEAK_HBM_GBS,
+                 "traffic_GB_per_s": (pmc["traffic"] / sec / 1e9) if (pmc["traffic"] and sec > 0 and not stored) else None,
+                 "traffic_frac_of_peak": (pmc["traffic"] / sec / 1e9 / PEAK_HBM_GBS) if (pmc["traffic"] and sec > 0 and not stored) else None}}
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +230,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c4", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true", help="skip the gene-trees/s leg (NJ + NNI search of every gene)")
+    ap.add_argument("--no-c4", action="store_true", help="skip the c4_shard / c4_strong record (also BENCH_NO_C4=1)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--genes", type=int, default=0, help="strong scaling: total genes of the job (default 500 for c4, 128 for c3, 16 for tiny)")
     args = ap.parse_args()
@@ -166,14 +249,14 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from pepr_amd import distributed as pd, engine, synth
+    from pepr_amd import distributed as pd, engine
 
     # rehearsal knobs (not used by the driver): BENCH_BACKEND=gloo + BENCH_FORCE_DEVICE=0 let two
     # ranks share the one GPU of a test box to exercise the N>1 path
     rank, local, world = pd.init_from_env(os.environ.get("BENCH_BACKEND"))
     if "BENCH_FORCE_DEVICE" in os.environ:
         local = int(os.environ["BENCH_FORCE_DEVICE"])
-    ntax, nsites, per_gpu = {"c3": (50, 1000, 128), "c4": (200, 5000, 63), "tiny": (12, 200, 8)}[args.workload]
+    ntax, nsites, per_gpu = SHAPES[args.workload]
     alpha = 0.8
     strong = args.scaling == "strong"
     if strong:
@@ -183,86 +266,129 @@ def main():
     else:
         total = per_gpu * world
         gene_ids = [rank * per_gpu + i for i in range(per_gpu)]            # contiguous shard of the global list
-    genes = [synth.simulate_alignment(ntax, nsites, 1 + gid, alpha) for gid in gene_ids]
-    # CPU baseline first (rank 0, N=1 only): worker processes are spawned before this process
-    # touches the GPU
+    want_c4 = not (args.no_c4 or os.environ.get("BENCH_NO_C4") or strong) and (args.workload == "c3" or bool(os.environ.get("BENCH_FORCE_C4")))
+    # everything that needs host worker processes happens first, before this process touches the GPU: the synthetic genes
+    # (both workloads) and the CPU baseline (rank 0, N=1 only)
+    genes = simulate(ntax, nsites, gene_ids, alpha)
+    c4_ids, c4_genes = [], []
+    if want_c4:
+        c4_ids = pd.shard_by_cost([200 * 5000] * 500, rank if world > 1 else 0, world if world > 1 else 8)
+        if os.environ.get("BENCH_C4_GENES"):                 # rehearsal knob: a smaller job (tests)
+            c4_ids = pd.shard_by_cost([200 * 5000] * int(os.environ["BENCH_C4_GENES"]), rank, world)
+        c4_genes = simulate(*[int(x) for x in os.environ.get("BENCH_C4_SHAPE", "200,5000").split(",")], c4_ids, alpha)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(genes, alpha, float(os.environ.get("BENCH_CPU_SECONDS", "12")))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     torch.cuda.set_device(local)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def rank_max(*vals):
+        if world == 1:
+            return [float(v) for v in vals]
+        t = torch.tensor(list(vals), dtype=torch.float64, device=pd._device())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t]
+
+    def score_legs(ctx, G, ids, steps, warmup, clock_warmup_s, stored_leg):
+        """The timed scoring region over this rank's genes G (resident sub-batches when they do not fit at once; every rank the
+        same number so that the barriers pair up).  Returns seconds (max over ranks), patterns of this rank, and the kernel
+        statistics of the timed steps -- for the default (register-resident) pass, for the K steps before the clock warm-up,
+        and for the stored traversal."""
+        free_b = torch.cuda.mem_get_info()[0]
+        nt, ns = len(G[0][0]), len(G[0][1][0])
+        gene_bytes = (3 * nt + 12) * 640 * (ns + 32)
+        nchunks = max(1, -(-len(G) * gene_bytes // int(0.8 * free_b)))
+        if world > 1:
+            nchunks = pd._world_max(nchunks)
+        chunks = [list(c) for c in np.array_split(np.arange(len(G)), nchunks)]
+        res = {"dt": 0.0, "dt_cold": 0.0, "dt_stored": 0.0, "npat": 0, "nchunks": nchunks, "clock_warmup_steps": 0, "first_step_ms": None,
+               "lnl": [], "stats": None, "stats_stored": None}
+        for ci, idx in enumerate(chunks):
+            sub = [G[i] for i in idx]
+            t_first = time.perf_counter()
+            batch = engine.Batch(ctx, [(g[0], g[1]) for g in sub], [g[2] for g in sub], alpha=alpha) if sub else None
+            res["npat"] += sum(batch.npatterns()) if batch else 0
+            rec_ids = [ids[i] for i in idx] + [-1] * (len(chunks[0]) - len(idx))     # equal record counts per rank
+
+            def step(stored=False):
+                return batch.score(stored) if batch else np.zeros(0)          # ends with the results on this rank's host (synchronised)
+
+            def gather(lnls):
+                # THE one gather of per-gene results of a job (RCCL over xGMI; SURVEY 8e): the K passes of the timed region are
+                # one job, their K x genes records go to rank 0 in ONE collective, inside the timed region.  (A gather per
+                # 1-ms pass would price the plumbing a thousand times higher than the real job does: one gather per tree build.)
+                if world > 1:
+                    lnls = lnls or [np.zeros(0)]
+                    pd.gather_results(rec_ids * len(lnls), np.concatenate([np.concatenate([l, np.zeros(len(rec_ids) - len(l))]) for l in lnls]))
+
+            def timed(k, stored=False):
+                sync_all()
+                t0 = time.perf_counter()
+                out = [step(stored) for _ in range(k)]
+                gather(out)
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                return time.perf_counter() - t0, out
+
+            lnl = None
+            for w in range(warmup):
+                lnl = step()
+                if ci == 0 and w == 0:
+                    res["first_step_ms"] = (time.perf_counter() - t_first) * 1e3      # batch creation (encode, arena, H2D) + the first pass
+            gather([lnl] if warmup else [])              # also brings the communicator up before the clock starts
+            # cold: exactly the contract's region -- K steps right behind the W warm-up steps
+            d, _ = timed(steps)
+            res["dt_cold"] += d
+            # a fresh box needs a second or so of load before the chip and the host hold their clocks (the first processes after
+            # box start measured 1.07 s for the search that later takes 0.83 s, profiles/r02_ab_search_warmup.txt): the same
+            # untimed step, repeated until clock_warmup_s have passed; `value` is the steady state behind it, `cold` the K steps before
+            t_w = time.perf_counter()
+            while ci == 0 and batch and time.perf_counter() - t_w < clock_warmup_s:
+                batch.score(); res["clock_warmup_steps"] += 1          # no collective here: every rank loops on its own clock
+            if ci == 0:
+                ctx.kernel_stats(reset=True)
+            d, out = timed(steps)
+            res["dt"] += d
+            res["lnl"].append(out[-1])
+            if ci == 0:
+                res["stats"] = ctx.kernel_stats(reset=True)
+            if stored_leg:
+                for _ in range(max(warmup, 1)):
+                    lnl_s = step(True)                   # records the stored plan
+                assert np.array_equal(lnl_s, out[-1]), "the stored traversal must return the bits of the register-resident one"
+                if ci == 0:
+                    ctx.kernel_stats(reset=True)
+                d, _ = timed(steps, True)
+                res["dt_stored"] += d
+                if ci == 0:
+                    res["stats_stored"] = ctx.kernel_stats(reset=True)
+            if batch:
+                batch.close()
+        assert np.all(np.isfinite(np.concatenate(res["lnl"])))
+        res["dt"], res["dt_cold"], res["dt_stored"] = rank_max(res["dt"], res["dt_cold"], res["dt_stored"])
+        if world > 1:
+            t = torch.tensor([float(res["npat"])], dtype=torch.float64, device=pd._device())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            res["npat_all"] = float(t[0])
+        else:
+            res["npat_all"] = float(res["npat"])
+        return res
+
     ctx = engine.Context(local, profile=True)
-    # resident sub-batches: the rank's genes are scored from HBM-resident batches; a share that does not fit at once
-    # (strong scaling at small N: 500 C4 genes = 950 GB of CLVs) goes through in consecutive resident sub-batches, every
-    # rank the same number of them so that the barriers pair up; the default workloads are ONE sub-batch
-    free_b = torch.cuda.mem_get_info()[0]
-    gene_bytes = (3 * ntax + 12) * 640 * (nsites + 32)
-    nchunks = max(1, -(-len(genes) * gene_bytes // int(0.8 * free_b)))
-    if world > 1:
-        nchunks = pd._world_max(nchunks)
-    chunks = [list(c) for c in np.array_split(np.arange(len(genes)), nchunks)]
-    dt, npat, lnl_all = 0.0, 0, []
-    stats = None
-    CLOCK_WARMUP_S = float(os.environ.get("BENCH_CLOCK_WARMUP_S", "1.5"))
-    clock_warmup_steps = 0
-    for ci, idx in enumerate(chunks):
-        sub = [genes[i] for i in idx]
-        batch = engine.Batch(ctx, [(g[0], g[1]) for g in sub], [g[2] for g in sub], alpha=alpha) if sub else None
-        npat += sum(batch.npatterns()) if batch else 0
-        ids = [gene_ids[i] for i in idx] + [-1] * (len(chunks[0]) - len(idx))     # equal record counts per rank
-
-        def step():
-            return batch.score() if batch else np.zeros(0)          # ends with the results on this rank's host (synchronised)
-
-        def gather(lnls):
-            # THE one gather of per-gene results of a job (RCCL over xGMI): the K passes of the timed region are
-            # one job, their K x genes records go to rank 0 in ONE collective, inside the timed region.  (A gather per
-            # 1-ms pass would price the plumbing a thousand times higher than the real job does: one gather per tree build.)
-            if world > 1:
-                lnls = lnls or [np.zeros(0)]
-                k = len(lnls)
-                pd.gather_results(ids * k, np.concatenate([np.concatenate([l, np.zeros(len(ids) - len(l))]) for l in lnls]))
-
-        for _ in range(args.warmup):
-            lnl = step()
-        gather([lnl] if args.warmup else [])              # also brings the communicator up before the clock starts
-        # a fresh box needs a second or so of load before the chip and the host hold their clocks (the first processes after
-        # box start measured 1.07 s for the search that later takes 0.83 s, profiles/r02_ab_search_warmup.txt): the same
-        # untimed step, repeated until CLOCK_WARMUP_S have passed
-        t_w = time.perf_counter()
-        while ci == 0 and batch and time.perf_counter() - t_w < CLOCK_WARMUP_S:
-            batch.score(); clock_warmup_steps += 1          # no collective here: every rank loops on its own clock
-        if ci == 0:
-            ctx.kernel_stats(reset=True)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        timed = []
-        for _ in range(args.steps):
-            lnl = step(); timed.append(lnl)
-        gather(timed)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt += time.perf_counter() - t0
-        lnl_all.append(lnl)
-        if batch:
-            batch.close()
-    stats = ctx.kernel_stats()
-    assert np.all(np.isfinite(np.concatenate(lnl_all)))
-
-    tot_pat = npat
-    if world > 1:
-        t = torch.tensor([dt, float(npat)], dtype=torch.float64, device=pd._device())
-        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt, tot_pat = float(tmax[0]), float(tsum[1])
+    S = score_legs(ctx, genes, gene_ids, args.steps, args.warmup, float(os.environ.get("BENCH_CLOCK_WARMUP_S", "1.5")), True)
+    ctx.close()
+    nchunks, npat, tot_pat, dt = S["nchunks"], S["npat"], S["npat_all"], S["dt"]
 
     # second metric of BASELINE.json: complete tree inferences per second (NJ start, model
     # optimisation, NNI hill climbing), every gene of the shard, one batched call
-    search = None
+    search, spr = None, None
     if not args.no_search:
         sctx = engine.Context(local)           # no per-kernel HIP events in the timed search
         G = [(g[0], g[1]) for g in genes]
@@ -270,9 +396,7 @@ def main():
         def infer():
             """one complete inference of every gene of the shard: encode + pattern compression, NJ start trees,
             device arena, model optimisation, NNI search; returns (seconds, setup seconds, lnl, batch)"""
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
+            sync_all()
             t0 = time.perf_counter()
             if nchunks > 1:                 # does not fit at once: the one-shot call walks it in HBM-sized sub-batches
                 out = sctx.search(G, None, nni=True, spr_radius=0, epsilon=1e-3)
@@ -298,27 +422,19 @@ def main():
         rf = [engine.rf_distance(genes[i][2], sb.newick(i)) for i in range(len(genes))]
         sb.close()
         # the RAxML-path search (`raxmlHPC -f d`): parsimony start trees + NNI + lazy SPR radius 5, one one-shot call
-        spr = None
         if ntax <= 64 and not os.environ.get("BENCH_NO_SPR"):
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
+            sync_all()
             t0 = time.perf_counter()
             sout = sctx.search(G, None, nni=True, spr_radius=5, epsilon=1e-3, seed=12345)
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
-            tspr = time.perf_counter() - t0
-            if world > 1:
-                t = torch.tensor([tspr], dtype=torch.float64, device=pd._device())
-                dist.all_reduce(t, op=dist.ReduceOp.MAX); tspr = float(t[0])
+            tspr, = rank_max(time.perf_counter() - t0)
             spr = {"gene_trees_per_sec": total / tspr, "seconds": tspr,
                    "algorithm": "randomised stepwise-addition parsimony start + model optimisation + NNI + lazy SPR (radius 5), eps 1e-3",
                    "rf_to_generating_tree_mean_rank0": float(np.mean([engine.rf_distance(genes[i][2], sout[i]["newick"]) for i in range(len(genes))]))}
         sctx.close()
-        if world > 1:
-            t = torch.tensor([sdt, cold], dtype=torch.float64, device=pd._device())
-            dist.all_reduce(t, op=dist.ReduceOp.MAX); sdt, cold = float(t[0]), float(t[1])
+        sdt, cold = rank_max(sdt, cold)
         search = {"gene_trees_per_sec": total / sdt, "seconds": sdt, "setup_seconds_rank0": tc,
                   "cold_first_call_seconds": cold, "cold_gene_trees_per_sec": total / cold, "second_call_seconds_rank0": warm1, "genes": total,
                   "algorithm": "NJ start + WAG+G4 model optimisation + NNI hill climbing (eps 1e-3); timed from host char rows to Newick",
@@ -328,60 +444,113 @@ def main():
                                  "algorithmic_GB": {k: v["algo_bytes"] / 1e9 for k, v in sst.items() if v["algo_bytes"]},
                                  "algorithmic_TB_per_s": sum(v["algo_bytes"] for k, v in sst.items() if k in ("newview", "newton")) / sdt / 1e12}}
 
+    # BASELINE config[3] (200 taxa x 5000 sites x 500 genes over 8 GPUs): at N = 1 this GPU's share of it (the 63 genes rank 0
+    # of 8 gets), at N > 1 the whole 500-gene job dealt by cost over the N ranks, with the ONE gather of the result records
+    c4 = None
+    if want_c4 and c4_genes:
+        c4 = c4_record(engine, pd, dist, torch, np, c4_genes, c4_ids, rank, local, world, alpha, sync_all, rank_max, score_legs)
+
     if rank == 0:
-        nv = stats["newview"]
-        avg_ms = nv["ms"] / max(nv["launches"], 1)
-        achieved = nv["algo_bytes"] / max(nv["launches"], 1) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM bytes per launch: rocprofv3 --pmc cannot run inside this process, so this is the COMMITTED counter
-        # measurement of this same command (profiles/, named in traffic_source), not a value measured in this run
-        traffic, traffic_src = None, None
-        for name in ("r02_pmc_traffic_%s.json" % args.workload, "r01_pmc_traffic_%s.json" % args.workload):
-            pmc = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(pmc) and not strong:
-                traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
-                traffic_src = "committed PMC passes, profiles/" + name
-                break
-        algo_flops = float(npat) / max(nchunks, 1) * (6480.0 * (ntax - 2) + 3360.0)      # one launch = one resident sub-batch of rank 0
-        pipe_busy = None
-        pb = os.path.join(ROOT, "profiles", "r02_pmc_k_oplist_chained_%s.json" % args.workload)
-        if os.path.exists(pb) and not strong:
-            pipe_busy = json.load(open(pb))["derived"]["mfma_pipe_busy_frac"]
+        pmc = committed_pmc(args.workload) if not strong else committed_pmc("none")
+        upper = float(npat) / max(nchunks, 1) * (6480.0 * (ntax - 2) + 3360.0)      # one launch = one resident sub-batch of rank 0
+        stats = S["stats"]
         out = {
             "metric": "M site-lnL/sec (WAG+G4 full-tree likelihood evaluations x alignment patterns); the gene-trees/sec half of BASELINE.json's metric is search.gene_trees_per_sec",
             "value": tot_pat * args.steps / dt / 1e6, "unit": "M site-lnL/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_warmup_steps": clock_warmup_steps,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_warmup_steps": S["clock_warmup_steps"],
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "commit": git_head(),
             "config": {"workload": "%s: %s x %d taxa x %d AA sites, WAG+G4 (RAxML PROTGAMMAWAG conventions), seeds 1..G" % (
                 args.workload, ("%d genes in all, block-cyclic by cost" % total) if strong else ("%d genes/GPU" % per_gpu), ntax, nsites),
                 "patterns_rank0": npat, "genes_total": total, "resident_sub_batches_per_rank": nchunks,
                 "parallelism": "gene-sharded x%d" % world},
-            # Since register chaining a scoring launch moves a fraction of SURVEY 8d's bytes (a child that
-            # its parent consumes next never leaves the registers), so the pass sits under SURVEY 8d's OTHER roofline, the
-            # f64 matrix pipe ("the fused scorer ... then the bound is flops"): achieved = 8d's flops per site-lnL
-            # (6480 (n-2) + 3360) x the patterns of a launch / the launch's HIP-event time; peak = 78.6 TFLOP/s (vendor FP64
-            # matrix figure SURVEY 8d uses; MI355X_MICROARCH.md lists none for f64; v_mfma_f64_4x4x4 measured 62-67 on the
-            # box, profiles/r01_ubench_f64.txt).  "hbm" keeps the previous accounting beside it: frac = 8d's bytes / time /
-            # 8 TB/s (above 1: bytes that are no longer moved), frac_traffic = counter bytes / time / 8 TB/s.
-            "roofline": {"bound": "mfma", "kernel": "k_oplist (newview+evaluate)", "achieved": algo_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
-                         "peak": 78.6, "unit": "TFLOP/s", "frac": (algo_flops / (avg_ms * 1e-3) / 78.6e12) if avg_ms > 0 else 0.0,
-                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms,
-                         "algo_flops_per_launch": algo_flops, "matrix_pipe_busy_frac_pmc": pipe_busy,
-                         "hbm": {"achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                                 "frac_traffic": (traffic / (avg_ms * 1e-3) / 8e12) if (traffic and avg_ms > 0) else None,
-                                 "algo_bytes_per_launch": nv["algo_bytes"] / max(nv["launches"], 1)}},
+            # the K steps right behind the W warm-up steps (the contract's region to the letter); `value` is the steady state after
+            # `clock_warmup_steps` more untimed steps (a fresh box holds its clocks only after ~1 s of load)
+            "cold": {"value": tot_pat * args.steps / S["dt_cold"] / 1e6, "ms_per_step": S["dt_cold"] / args.steps * 1e3,
+                     "first_step_ms_rank0": S["first_step_ms"], "note": "first_step = batch creation (encode, arena, upload) + plan recording + one pass"},
+            "roofline": roofline_of(stats["newview"], pmc, upper),
             "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in stats.items() if v["launches"]},
         }
+        if S["stats_stored"] is not None and S["dt_stored"] > 0:
+            # second timed leg: the traversal a search runs -- chained children are READ from registers but every CLV is written
+            # (later partial traversals read them back); same lnL bits (asserted above)
+            out["stored_traversal"] = {"value": tot_pat * args.steps / S["dt_stored"] / 1e6, "unit": "M site-lnL/s",
+                                       "ms_per_step": S["dt_stored"] / args.steps * 1e3,
+                                       "roofline": roofline_of(S["stats_stored"]["newview"], pmc, upper, stored=True),
+                                       "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in S["stats_stored"].items() if v["launches"]}}
         if search is not None:
             out["search"] = search
             if spr is not None:
                 out["search_raxml_path"] = spr
+        if c4 is not None:
+            out["c4_strong" if world > 1 else "c4_shard"] = c4
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def c4_record(engine, pd, dist, torch, np, genes, ids, rank, local, world, alpha, sync_all, rank_max, score_legs):
+    """BASELINE config[3] at this N: scoring (M site-lnL/s), NNI search and NNI + lazy SPR (gene-trees/s) of this rank's
+    share of the 500-gene job, per-rank seconds (max / min) and the time of the one gather of {id, status, lnL, alpha, tree
+    length, Newick} records to rank 0."""
+    nt, ns = len(genes[0][0]), len(genes[0][1][0])
+    ctx = engine.Context(local, profile=True)
+    S = score_legs(ctx, genes, ids, 10, 2, 0.0, False)
+    ctx.close()
+    total = len(ids)
+    if world > 1:
+        t = torch.tensor([float(total)], dtype=torch.float64, device=pd._device()); dist.all_reduce(t, op=dist.ReduceOp.SUM); total = int(t[0])
+    rec = {"config": "BASELINE configs[3]: %d genes x %d taxa x %d sites %s" % (total, nt, ns, "dealt by cost over %d ranks (strong scaling)" % world if world > 1 else
+                     "= the share rank 0 of 8 gets of the 500-gene job, on this one GPU"),
+           "genes_rank0": len(ids), "patterns_rank0": S["npat"], "resident_sub_batches_per_rank": S["nchunks"],
+           "score": {"value": S["npat_all"] * 10 / S["dt"] / 1e6, "unit": "M site-lnL/s", "ms_per_step": S["dt"] / 10 * 1e3, "steps": 10,
+                     "roofline": roofline_of(S["stats"]["newview"], committed_pmc("c4"), float(S["npat"]) / S["nchunks"] * (6480.0 * (nt - 2) + 3360.0))}}
+    sctx = engine.Context(local)
+    G = [(g[0], g[1]) for g in genes]
+    per = max(pd._world_max(len(ids)), 1) if world > 1 else len(ids)
+    pad_ids = ids + [-1] * (per - len(ids))
+
+    def job(radius, seed):
+        sync_all()
+        t0 = time.perf_counter()
+        out = sctx.search(G, None, nni=True, spr_radius=radius, epsilon=1e-3, seed=seed) if G else []
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
+        tg = time.perf_counter()
+        pad = per - len(out)
+        got = pd.gather_results(pad_ids, np.array([o["lnl"] for o in out] + [0.0] * pad), alpha=np.array([o["alpha"] for o in out] + [0.0] * pad),
+                                tree_length=np.array([o["tree_length"] for o in out] + [0.0] * pad), newicks=[o["newick"] for o in out] + [""] * pad,
+                                status=[0] * per)
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        if world > 1:
+            dist.barrier()
+        wall = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([mine], dtype=torch.float64, device=pd._device())
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            secs = [float(x[0]) for x in allt]
+        else:
+            secs = [mine]
+        wall, = rank_max(wall)
+        r = {"gene_trees_per_sec": total / wall, "seconds": wall, "rank_seconds_max": max(secs), "rank_seconds_min": min(secs), "gather_ms_rank0": gather_ms,
+             "rf_to_generating_tree_mean_rank0": float(np.mean([engine.rf_distance(genes[i][2], out[i]["newick"]) for i in range(len(out))])) if out else None}
+        if rank == 0 and got is not None:
+            r["records_gathered"] = len(got)
+            assert len(got) == total and all(np.isfinite(v["lnl"]) and v["status"] == 0 for v in got.values())
+        return r
+    rec["search_nni"] = job(0, 0)
+    rec["search_nni"]["algorithm"] = "NJ start + model optimisation + NNI (eps 1e-3), host char rows -> Newick, first call of the context (cold arena)"
+    if (len(ids) <= 64 or os.environ.get("BENCH_C4_SPR")) and not os.environ.get("BENCH_NO_SPR"):
+        rec["search_nni_spr5"] = job(5, 12345)
+        rec["search_nni_spr5"]["algorithm"] = "parsimony start + model optimisation + NNI + lazy SPR radius 5 (eps 1e-3), the RAxML path"
+    else:
+        rec["search_nni_spr5"] = None
+        rec["search_nni_spr5_skipped"] = "more than 64 genes per rank: several HBM sub-batches of ~21 s each; BENCH_C4_SPR=1 runs it"
+    sctx.close()
+    return rec
 
 
 if __name__ == "__main__":

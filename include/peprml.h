@@ -143,6 +143,9 @@ int  pml_batch_size(const pml_batch *b);
 int  pml_batch_npatterns(const pml_batch *b, int gene);
 /* full post-order CLV pass + root evaluation for every gene (all CLVs recomputed) */
 int  pml_batch_score(pml_batch *b, double *lnl_out /* n */);
+/* the same pass with every CLV WRITTEN to HBM (a child its parent consumes next is still read from registers): the whole-tree
+ * traversal a search runs after a topology or alpha change, where later partial traversals read the CLVs back; same lnL bits */
+int  pml_batch_score_stored(pml_batch *b, double *lnl_out /* n */);
 int  pml_batch_site_lnl(pml_batch *b, int gene, double *site_lnl /* nsites */);
 int  pml_batch_set_alpha(pml_batch *b, int gene /* -1 = all */, double alpha);
 int  pml_batch_optimize(pml_batch *b, const pml_search_opts *opts, double *lnl_out, double *alpha_out);
@@ -181,6 +184,17 @@ typedef struct {
 int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *genes, const pml_model *model,
                   const pml_jackknife_opts *opts, pml_result *main_out /* newick carries the supports */,
                   char **support_newicks_out /* optional: reps lines, '\n'-separated; pml_free */);
+/* host-only: the gene subsets pml_jackknife draws for (ngenes, reps, subset_size, seed) -- replicate r = sel_out[r*k .. r*k+k),
+ * ascending gene indices, k = the return value (subset_size, or ngenes/2 when 0; < 0 = error).  The reference draws them with
+ * RandomSetUtils.getRandomSet (.../pepr/util/RandomSetUtils.java:9-35, unseeded java.util.Random); callers that need to know
+ * which genes a support tree was built from (reports, the oracle-side parity test) get the seeded draw here. */
+int pml_jackknife_draw(int ngenes, int reps, int subset_size, unsigned long long seed, int *sel_out /* reps x k */);
+/* test hook for the device-side concatenation (MSAConcatenator.java:78-189): encodes the genes into HBM, gathers
+ * the selection `sel` (NULL = all) on the device exactly as pml_jackknife does for a replicate, and reads the result back:
+ * codes_out[ntax x mpad] (0..19 = ARNDCQEGHILKMFPSTWYV, 20 = B, 21 = Z, 22 = gap/unknown), weights_out[mpad] (0 = padding),
+ * names_out = the sorted taxon union, one per line.  The three buffers are released with pml_free. */
+int pml_debug_gather(pml_ctx *ctx, int ngenes, const pml_alignment *genes, int nsel, const int *sel, int *ntax_out,
+                     int *npat_out, int *mpad_out, unsigned char **codes_out, double **weights_out, char **names_out);
 /* host-only: the refinement loop's support queries on a rooted Newick with support labels (")95:0.1" or
  * ":0.1[95]"; missing = 100, fractions are x100) -- PhylogeneticTreeRefiner.java:298-359 getNextIndexToRefine,
  * AdvancedTree.java:1061-1098 getMeanDescendantSupportValues.  *ingroup_out = comma-joined sorted leaf names of
@@ -241,6 +255,9 @@ enum { PML_K_PMAT = 0, PML_K_NEWVIEW = 1, PML_K_EVALUATE = 2, PML_K_SUMTABLE = 3
        PML_K_HOST_BUILD = 6 /* CPU ms building descriptors */, PML_K_HOST_WAIT = 7 /* CPU ms in stream sync */, PML_K_COUNT = 8 };
 int pml_kernel_stats(pml_ctx *ctx, int kernel, long long *launches, double *total_ms,
                      double *algo_bytes /* algorithmic bytes moved, SURVEY 8d figures */);
+/* algorithmic flops of the launches counted by pml_kernel_stats, SURVEY 8d's per-operation figures (newview inner-inner 6480,
+ * tip-inner 3280, tip-tip 80, evaluate 3360 flop per pattern; a sumtable = an inner-inner contraction) */
+int pml_kernel_flops(pml_ctx *ctx, int kernel, double *algo_flops);
 int pml_kernel_stats_reset(pml_ctx *ctx);
 
 #ifdef __cplusplus

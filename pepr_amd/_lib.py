@@ -16,9 +16,9 @@ SYMBOLS = [
     "pml_score", "pml_optimize", "pml_search",
     "pml_score_batch", "pml_optimize_batch", "pml_search_batch", "pml_result_free",
     "pml_batch_create", "pml_batch_destroy", "pml_batch_size", "pml_batch_npatterns",
-    "pml_batch_score", "pml_batch_site_lnl", "pml_batch_set_alpha", "pml_batch_optimize",
+    "pml_batch_score", "pml_batch_score_stored", "pml_batch_site_lnl", "pml_batch_set_alpha", "pml_batch_optimize",
     "pml_batch_search", "pml_batch_newick", "pml_batch_root_derivs", "pml_free",
-    "pml_rf_distance", "pml_support_tree", "pml_jackknife", "pml_concatenate", "pml_parsimony", "pml_parsimony_batch", "pml_refine_next", "pml_bootstrap", "pml_coalescing_stats", "pml_sh_support", "pml_sh_support_batch", "pml_gamma20", "pml_gamma20_batch", "pml_debug_fpenv", "pml_kernel_stats", "pml_kernel_stats_reset",
+    "pml_rf_distance", "pml_support_tree", "pml_jackknife", "pml_jackknife_draw", "pml_debug_gather", "pml_concatenate", "pml_parsimony", "pml_parsimony_batch", "pml_refine_next", "pml_bootstrap", "pml_coalescing_stats", "pml_sh_support", "pml_sh_support_batch", "pml_gamma20", "pml_gamma20_batch", "pml_debug_fpenv", "pml_kernel_stats", "pml_kernel_flops", "pml_kernel_stats_reset",
 ]
 
 
@@ -95,6 +95,7 @@ def load():
     L.pml_batch_size.argtypes = [vp]
     L.pml_batch_npatterns.argtypes = [vp, C.c_int]
     L.pml_batch_score.argtypes = [vp, dp]
+    L.pml_batch_score_stored.argtypes = [vp, dp]
     L.pml_batch_site_lnl.argtypes = [vp, C.c_int, dp]
     L.pml_batch_set_alpha.argtypes = [vp, C.c_int, C.c_double]
     L.pml_batch_optimize.argtypes = [vp, sp, dp, dp]
@@ -106,6 +107,8 @@ def load():
     L.pml_rf_distance.argtypes = [C.c_char_p, C.c_char_p, ip]
     L.pml_support_tree.argtypes = [C.c_char_p, C.c_int, cpp, C.c_int, C.POINTER(vp)]
     L.pml_jackknife.argtypes = [vp, C.c_int, ap, mp, C.POINTER(JackknifeOpts), rp, C.POINTER(vp)]
+    L.pml_jackknife_draw.argtypes = [C.c_int, C.c_int, C.c_int, C.c_ulonglong, ip]
+    L.pml_debug_gather.argtypes = [vp, C.c_int, ap, C.c_int, ip, ip, ip, ip, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.pml_parsimony.argtypes = [vp, ap, C.POINTER(ParsimonyOpts), rp, C.POINTER(C.c_longlong)]
     L.pml_parsimony_batch.argtypes = [vp, C.c_int, ap, C.POINTER(ParsimonyOpts), rp, C.POINTER(C.c_longlong)]
     L.pml_refine_next.argtypes = [C.c_char_p, C.c_int, C.c_int, cpp, C.POINTER(vp), ip, C.POINTER(vp)]
@@ -117,6 +120,7 @@ def load():
     L.pml_debug_fpenv.argtypes = [C.POINTER(C.c_uint), C.c_int]
     L.pml_concatenate.argtypes = [C.c_int, ap, C.c_int, ip, C.POINTER(vp)]
     L.pml_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_longlong), dp, dp]
+    L.pml_kernel_flops.argtypes = [vp, C.c_int, dp]
     L.pml_kernel_stats_reset.argtypes = [vp]
     L.pml_coalescing_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     _lib = L

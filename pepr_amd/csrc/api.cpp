@@ -137,6 +137,12 @@ int pml_batch_score(pml_batch *b, double *lnl) {
     LOCKED(b);
     GUARD(b->b.score(std::vector<char>(), lnl));
 }
+int pml_batch_score_stored(pml_batch *b, double *lnl) {
+    if (!b || !lnl) return PML_EINVAL;
+    pml_fpguard fpg;
+    LOCKED(b);
+    GUARD(b->b.score(std::vector<char>(), lnl, true));
+}
 int pml_batch_site_lnl(pml_batch *b, int g, double *out) {
     if (!b || !out || g < 0 || g >= (int)b->b.genes.size()) return PML_EINVAL;
     pml_fpguard fpg;
@@ -449,15 +455,9 @@ int pml_sh_support(pml_ctx *ctx, const pml_alignment *aln, const char *newick, c
     return pml_sh_support_batch(ctx, 1, aln, &newick, model, nboot, seed, out);
 }
 
-int pml_gamma20_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks, const pml_model *model,
-                      pml_result *out, double *rescale_out) {
-    if (!ctx || !alns || !newicks || !out || n <= 0) return PML_EINVAL;
-    pml_fpguard fpg;
-    for (int i = 0; i < n; ++i) { std::memset(&out[i], 0, sizeof(pml_result)); if (!newicks[i]) return ctx->c.fail(PML_EINVAL, "newick required"); }
-    std::lock_guard<std::mutex> lk(ctx->c.mu);
+static int gamma20_chunk(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks, const pml_model &m,
+                         pml_result *out, double *rescale_out) {
     pml_batch *b = nullptr;
-    pml_model m = model ? *model : pml_model{4, 1.0, PML_PI_WAG_FULL};
-    m.ncat = 4;
     int rc = batch_create_impl(ctx, n, alns, newicks, &m, true, &b);
     if (rc) return rc;
     try {
@@ -475,6 +475,37 @@ int pml_gamma20_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const char
     } catch (const std::bad_alloc &) { rc = ctx->c.fail(PML_ENOMEM, "host allocation failed"); }
     catch (const std::exception &e) { rc = ctx->c.fail(PML_EINVAL, e.what()); }
     b->b.destroy(); delete b;
+    return rc;
+}
+
+int pml_gamma20_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const char *const *newicks, const pml_model *model,
+                      pml_result *out, double *rescale_out) {
+    if (!ctx || !alns || !newicks || !out || n <= 0) return PML_EINVAL;
+    pml_fpguard fpg;
+    for (int i = 0; i < n; ++i) { std::memset(&out[i], 0, sizeof(pml_result)); if (!newicks[i]) return ctx->c.fail(PML_EINVAL, "newick required"); }
+    std::lock_guard<std::mutex> lk(ctx->c.mu);
+    pml_model m = model ? *model : pml_model{4, 1.0, PML_PI_WAG_FULL};
+    m.ncat = 4;
+    // gene lists that do not fit in free HBM at once go through in consecutive sub-batches, like every other one-shot call
+    // (oneshot()); a gene needs its score-only arena plus the 20 x mpad likelihood table and 5 x mpad scaling counts
+    size_t free_b = 0, total_b = 0;
+    hipSetDevice(ctx->c.device);
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)1 << 40;
+    free_b += ctx->c.arena_cache_bytes;
+    size_t budget = (size_t)(0.85 * (double)free_b);
+    if (const char *e = std::getenv("PML_HBM_BUDGET_MB")) budget = (size_t)std::atoll(e) << 20;   // test hook
+    int rc = 0, begin = 0;
+    while (begin < n && !rc) {
+        size_t used = 0; int end = begin;
+        while (end < n) {
+            const size_t mp = ((size_t)std::max(alns[end].nsites, 1) + 31) / 32 * 32;
+            const size_t need = gene_bytes_bound(alns[end], true) + mp * (G20_RATES * 8 + (G20_RATES / 4) * 4) + 256;
+            if (end > begin && used + need > budget) break;
+            used += need; ++end;
+        }
+        rc = gamma20_chunk(ctx, end - begin, alns + begin, newicks + begin, m, out + begin, rescale_out ? rescale_out + begin : nullptr);
+        begin = end;
+    }
     for (int i = 0; i < n; ++i) out[i].status = rc;
     return rc;
 }
@@ -547,6 +578,12 @@ int pml_kernel_stats(pml_ctx *ctx, int k, long long *launches, double *ms, doubl
     if (launches) *launches = ctx->c.stats[k].launches;
     if (ms) *ms = ctx->c.stats[k].ms;
     if (bytes) *bytes = ctx->c.stats[k].bytes;
+    return PML_OK;
+}
+int pml_kernel_flops(pml_ctx *ctx, int k, double *flops) {
+    if (!ctx || !flops || k < 0 || k >= K_COUNT) return PML_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->c.mu);
+    *flops = ctx->c.stats[k].flops;
     return PML_OK;
 }
 int pml_kernel_stats_reset(pml_ctx *ctx) {

@@ -74,8 +74,8 @@ hipEvent_t Ctx::get_event() {
     if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
     hipEvent_t e; hipEventCreate(&e); return e;
 }
-void Ctx::tic(int kind, double bytes) {
-    stats[kind].launches++; stats[kind].bytes += bytes;
+void Ctx::tic(int kind, double bytes, double flops) {
+    stats[kind].launches++; stats[kind].bytes += bytes; stats[kind].flops += flops;
     if (!profile) return;
     Ev ev{kind, get_event(), get_event()};
     hipEventRecord(ev.a, tic_stream ? tic_stream : stream);
@@ -563,6 +563,9 @@ static double now_ms() {
 // one upload for all deferred steps (their descriptors are consecutive in the staging ring), then their launches in order
 int Batch::flush_deferred() {
     if (deferred.empty()) return 0;
+    // whatever happens below, the queue is empty afterwards and the event stream is reset: an error must not leave stale
+    // descriptors to be uploaded and launched again by the next chain_sync() / run()
+    struct Guard { Batch *b; ~Guard() { b->deferred.clear(); b->ctx->tic_stream = nullptr; } } guard{this};
     const size_t lo = deferred.front().base, hi = deferred.back().base + deferred.back().bytes;
     const hipStream_t cs = deferred.front().lane ? ctx->stream2 : ctx->stream;
     HIPCHK(hipMemcpyAsync((char *)d_stage + lo, (char *)h_stage + lo, hi - lo, hipMemcpyHostToDevice, cs));
@@ -581,7 +584,7 @@ int Batch::flush_deferred() {
             ctx->toc(); PML_SER();
         }
         if (L.nruns) {
-            ctx->tic(K_NEWVIEW, L.algo_bytes);
+            ctx->tic(K_NEWVIEW, L.algo_bytes, L.algo_flops);
             launch_oplist((const NvOp *)(ds + L.o_ops), (const GeneRun *)(ds + L.o_runs), (int)L.nruns, L.max_mpad, L.any_pitch, L.any_chain, st);
             ctx->toc(); PML_SER();
         }
@@ -597,8 +600,9 @@ int Batch::flush_deferred() {
             ctx->toc(); PML_SER();
         }
         ctx->tic_stream = nullptr;
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return ctx->fail(-5, std::string("kernel launch: ") + hipGetErrorString(e));
     }
-    deferred.clear();
+#undef PML_SER
     static const size_t flush_max = std::getenv("PML_FLUSH_MAX") ? (size_t)std::atoi(std::getenv("PML_FLUSH_MAX")) : 8;      // A-B arm
     flush_quota = std::min<size_t>(flush_quota * 2, flush_max);
     return 0;
@@ -661,7 +665,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     size_t nout = 0, nruns = 0, ie = 0, in = 0, ireq = 0, iop = 0;
     last_src.clear();
     int max_mpad = 0, newton_maxm = 0;
-    double algo_bytes = 0;
+    double algo_bytes = 0, algo_flops = 0;
     // one transition-matrix request (fragment set or tip table) for branch (v, slot q) of gene g
     // one request per (gene, kind, tree branch) and launch; never while a plan is being recorded (a replay refreshes
     // each request from ITS branch)
@@ -710,12 +714,17 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     // resolves one side of an op: pointers, kind, scaling counts; `want_table`: newview tip sides look
     // their contraction up in a tip table; `t_branch`/(bv,bq): the branch between this side and the op
     // node (fragment request), unless the caller supplies fixed matrices
-    struct Resolved { OpSide s; int kind; const int *scl; double bytes; };
+    // bytes / flops: SURVEY 8d's per-operation figures (newview inner-inner 1920 B / 6480 flop, tip-inner 1281 B / 3280 flop,
+    // tip-tip 642 B / 80 flop, evaluate 1280 B / 3360 flop per pattern).  `inner`: the side counts as an inner child of the
+    // operation; `flops`: work 8d assigns to producing a side that is never materialised (virtual cherry = one tip-tip newview,
+    // virtual pitchfork = that + one tip-inner newview)
+    struct Resolved { OpSide s; int kind; const int *scl; double bytes; double flops = 0; bool inner = true; };
     auto resolve = [&](size_t g, const Side &sd, Resolved &R) -> int {
         Gene &G = genes[g];
         const int mp = G.aln.mpad, nt = G.aln.ntax;
         R.s = OpSide{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; R.scl = nullptr;
-        if (sd.kind == SIDE_TIP) { R.kind = SK_TIP; R.s.p0 = G.d_codes + (size_t)sd.id * mp; R.bytes = 1; return 0; }
+        R.flops = 0; R.inner = true;
+        if (sd.kind == SIDE_TIP) { R.kind = SK_TIP; R.s.p0 = G.d_codes + (size_t)sd.id * mp; R.bytes = 1; R.inner = false; return 0; }
         if (sd.kind == SIDE_CHERRY) {
             const int v = nt + sd.id / 3, k = sd.id % 3;
             int tips[2], qs[2], ci = 0;
@@ -725,6 +734,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             R.s.t0 = add_req(g, G.tree.len[v][qs[0]], PM_TIPTABLE, v, qs[0]);
             R.s.t1 = add_req(g, G.tree.len[v][qs[1]], PM_TIPTABLE, v, qs[1]);
             R.bytes = 640 + 642;       // SURVEY 8d accounting: the tip-tip newview (642 B) + reading its CLV (640 B)
+            R.flops = 80;
             return 0;
         }
         if (sd.kind == SIDE_PITCH) {
@@ -744,6 +754,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             R.s.f = add_req(g, G.tree.len[X][qC], PM_FRAGS, X, qC);
             any_pitch = true;
             R.bytes = 640 + (640 + 642) + 1 + 640;   // read X + X's newview (cherry child, tip child, write)
+            R.flops = 80 + 3280;
             return 0;
         }
         const int slot = sd.kind == SIDE_MSG ? G.slot_of[sd.id] : G.slot_cap + sd.id;
@@ -776,7 +787,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         // (profiles/r02_ab_register_chaining.txt): C3 scoring launch 0.89 -> 0.72 ms, C4 shard 3.40 -> 2.92 ms, C3 search
         // 153 -> 161 gene-trees/s.
         static const int chain_env = std::getenv("PML_CHAIN") ? std::atoi(std::getenv("PML_CHAIN")) : 2;
-        const bool chain_reads = chain_env == 2 || (chain_env == 1 && record_plan), chain_nostore = chain_env >= 1 && record_plan;
+        const bool chain_reads = chain_env == 2 || (chain_env == 1 && record_plan), chain_nostore = chain_env >= 1 && record_plan && !record_stored;
         long last_nv = -1, last_nv_op = -1;            // hops / ops index of the gene's last newview
         auto chained_from = [&](const Side &sd, int kind) {
             return chain_reads && last_nv >= 0 && kind == SK_CLV && sd.kind == ops[last_nv_op].out_kind && sd.id == ops[last_nv_op].out_id;
@@ -800,6 +811,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
                 d.pl = d.pr = add_req(g, t.t0, PM_FRAGS_PI, t.bv, t.bq);
                 d.out = t.patlnl_dev; d.out_scl = t.scl_dev;
                 algo_bytes += (double)G.aln.npat * (L.bytes + R.bytes + 36);
+                algo_flops += (double)G.aln.npat * (3360 + L.flops + R.flops);
             } else if (t.mode == MODE_EVALUATE) {
                 d.pl = d.pr = add_req(g, t.t0, PM_FRAGS_PI, t.bv, t.bq);
                 double *pl = t.patlnl_dev ? t.patlnl_dev : G.d_patlnl[t.slot];      // pooled when a gene has more than MAXTAIL tails
@@ -807,6 +819,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
                 ReduceReq &rr = hred[ie++];
                 rr.patlnl = pl; rr.weight = G.d_weight; rr.out = result; rr.mpad = mp; rr.pad = 0;
                 algo_bytes += (double)G.aln.npat * (L.bytes + R.bytes + 8);
+                algo_flops += (double)G.aln.npat * (3360 + L.flops + R.flops);
             } else {
                 d.pl = eig; d.pr = eig + PFRAG;
                 double *stab = t.sumtab_dev ? t.sumtab_dev : G.d_sumtab[t.slot];
@@ -820,6 +833,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
                 nr.t_dev0 = t.t_dev0; nr.t_dev1 = t.t_dev1; nr.patlnl = t.patlnl_dev;
                 nr.sync = nsync_buf + (size_t)in * NEWTON_SYNC_DOUBLES; newton_maxm = std::max(newton_maxm, mp);
                 algo_bytes += (double)G.aln.npat * (L.bytes + R.bytes + 640);
+                algo_flops += (double)G.aln.npat * (6480 + L.flops + R.flops);      // the newview contraction with the eigen-basis matrices
                 in++;
             }
             return 0;
@@ -865,6 +879,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             if (chained_from(o.child[0], S[0].kind)) { d.flags |= OPF_CHAIN_L; consume_last(); }
             d.l = S[0].s; d.r = S[1].s; d.l_scl = S[0].scl; d.r_scl = S[1].scl; d.pl = pm[0]; d.pr = pm[1];
             algo_bytes += (double)G.aln.npat * (S[0].bytes + S[1].bytes + 640);
+            algo_flops += (double)G.aln.npat * ((S[0].inner && S[1].inner ? 6480 : (S[0].inner || S[1].inner ? 3280 : 80)) + S[0].flops + S[1].flops);
             last_nv = (long)nout - 1; last_nv_op = (long)iop;
             ++emitted;
             if (int rc = flush_tails(false)) return rc;
@@ -897,7 +912,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     Deferred L;
     L.base = base; L.bytes = bytes; L.o_req = o_req; L.o_ops = o_ops; L.o_runs = o_runs; L.o_red = o_red; L.o_newt = o_newt;
     L.nreq = ireq; L.nruns = nruns; L.neval = neval; L.nnewton = nnewton; L.max_mpad = max_mpad; L.newton_maxm = newton_maxm;
-    L.any_pitch = any_pitch; L.any_chain = any_chain; L.algo_bytes = algo_bytes; L.newton_bytes = newton_bytes; L.lane = lane; L.stagger = record_stagger;
+    L.any_pitch = any_pitch; L.any_chain = any_chain; L.algo_bytes = algo_bytes; L.algo_flops = algo_flops; L.newton_bytes = newton_bytes; L.lane = lane; L.stagger = record_stagger;
     record_stagger = false;
     // Inside a chained pass the upload + launches of a step are DEFERRED and issued in groups (1, 2, 4, 8, 8, ... steps):
     // a host-to-device copy between two kernels of one stream costs a ~20 us bubble on the compute queue (measured:
@@ -944,7 +959,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         // put the recorded rates back under the first replay (DESIGN r02-g: the cause of the rare different optimum)
         HIPCHK(hipMemcpyAsync(P.d, ds, bytes, hipMemcpyDeviceToDevice, ctx->stream));
         P.o_req = o_req; P.o_ops = o_ops; P.o_runs = o_runs; P.o_red = o_red;
-        P.nreq = ireq; P.nruns = nruns; P.neval = neval; P.max_mpad = max_mpad; P.algo_bytes = algo_bytes; P.any_pitch = any_pitch; P.any_chain = any_chain;
+        P.nreq = ireq; P.nruns = nruns; P.neval = neval; P.max_mpad = max_mpad; P.algo_bytes = algo_bytes; P.algo_flops = algo_flops; P.stored = record_stored; P.any_pitch = any_pitch; P.any_chain = any_chain;
         P.rates_seen.resize(genes.size()); for (size_t g = 0; g < genes.size(); ++g) P.rates_seen[g] = genes[g].rates_epoch;
         P.src = last_src; P.outs.clear();
         for (auto &o : ops) if (o.out_kind == SIDE_MSG && !o.unstored) P.outs.push_back({o.gene, o.out_id});
@@ -976,7 +991,7 @@ int Batch::replay_plan(double *lnl) {
     ctx->tic(K_PMAT, (double)P.nreq * PFRAG * 8);
     launch_pmat(md, (const PmatReq *)(ds + P.o_req), d_frags, (int)P.nreq, ctx->stream);
     ctx->toc();
-    ctx->tic(K_NEWVIEW, P.algo_bytes);
+    ctx->tic(K_NEWVIEW, P.algo_bytes, P.algo_flops);
     launch_oplist((const NvOp *)(ds + P.o_ops), (const GeneRun *)(ds + P.o_runs), (int)P.nruns, P.max_mpad, P.any_pitch, P.any_chain, ctx->stream);
     ctx->toc();
     ctx->tic(K_REDUCE, 0);
@@ -994,6 +1009,7 @@ int Batch::replay_plan(double *lnl) {
     }
     for (auto &o : P.outs) genes[o.first].valid[o.second] = 1;
     for (size_t g = 0; g < genes.size(); ++g) lnl[g] = res((int)g)[0];
+    if (!chain) for (size_t g = 0; g < genes.size(); ++g) if (!std::isfinite(lnl[g])) return ctx->fail(-5, "device returned a non-finite likelihood");
     for (size_t g = 0; g < genes.size(); ++g) det_record(det_id, genes[g], 'R', 0, 0, lnl[g], genes[g].alpha, 0);
     return 0;
 }
@@ -1016,16 +1032,16 @@ int Batch::evaluate(const std::vector<char> &active, double *lnl) {
     for (auto &t : tails) det_record(det_id, genes[t.gene], 'E', 0, 0, lnl[t.gene], genes[t.gene].alpha, 0);
     return 0;
 }
-int Batch::score(const std::vector<char> &active, double *lnl) {
+int Batch::score(const std::vector<char> &active, double *lnl, bool stored) {
     for (int g = 0; g < (int)genes.size(); ++g) if (active.empty() || active[g]) invalidate_all(g);
     bool all = true;
     for (char a : active) all = all && a;
     if (all && !score_only_batch) {
-        if (plan.valid && plan.epoch == topo_epoch) return replay_plan(lnl);
-        record_plan = true;
+        if (plan.valid && plan.epoch == topo_epoch && plan.stored == stored) return replay_plan(lnl);
+        record_plan = true; record_stored = stored;
     }
     const int rc = evaluate(active, lnl);
-    record_plan = false;
+    record_plan = false; record_stored = false;
     return rc;
 }
 int Batch::site_lnl(int g, double *out) {
@@ -1196,7 +1212,10 @@ int Batch::gamma20(std::vector<double> &lnl20, std::vector<double> &alpha20, std
     if (int rc = ensure_tailpool(bytes)) return rc;
     auto table = [&](int g) { return reinterpret_cast<double *>(d_tailpool + off[g]); };
     auto counts = [&](int g) { return reinterpret_cast<int *>(d_tailpool + off[g] + (size_t)genes[g].aln.mpad * G20_RATES * 8); };
+    // the genes carry FastTree's fixed rates only inside the loop below: whatever way it is left, they get their Gamma4 rates back
+    struct RatesBack { Batch *b; ~RatesBack() { for (int g = 0; g < (int)b->genes.size(); ++g) b->set_alpha(g, b->genes[g].alpha); } };
     for (int j = 0; j < G20_RATES / 4; ++j) {
+        RatesBack back{this};
         std::vector<PendingOp> ops; std::vector<Tail> tails;
         for (int g = 0; g < n; ++g) {
             Gene &G = genes[g];
@@ -1210,7 +1229,6 @@ int Batch::gamma20(std::vector<double> &lnl20, std::vector<double> &alpha20, std
         }
         if (int rc = run(ops, tails)) return rc;
     }
-    for (int g = 0; g < n; ++g) set_alpha(g, genes[g].alpha);            // back to the gene's Gamma4 rates
     if (int rc = ensure_results((size_t)n)) return rc;
     if (int rc = ensure_stage((size_t)n * sizeof(G20Req))) return rc;
     std::vector<double> la(n, 0.0), lm(n, 0.0), f(n, 0.0);               // log alpha, log mult, -lnL

@@ -26,7 +26,7 @@ struct Ctx {
     bool model_ready[2] = {false, false};
     ModelDev *d_model[2] = {nullptr, nullptr};
     double *d_eigfrags[2] = {nullptr, nullptr};   // 2*PFRAG doubles each
-    struct KStat { long long launches = 0; double ms = 0; double bytes = 0; } stats[K_COUNT];
+    struct KStat { long long launches = 0; double ms = 0; double bytes = 0; double flops = 0; } stats[K_COUNT];
     struct Ev { int kind; hipEvent_t a, b; };
     std::vector<Ev> pending;
     std::vector<hipEvent_t> pool;
@@ -40,7 +40,7 @@ struct Ctx {
     int ensure_model(int pi_mode);
     hipEvent_t get_event();
     hipStream_t tic_stream = nullptr;    // stream the next tic/toc pair is recorded on (null = stream)
-    void tic(int kind, double bytes);   // record start (profile mode)
+    void tic(int kind, double bytes, double flops = 0);   // record start (profile mode); bytes / flops = SURVEY 8d per-operation figures
     void toc();                          // record stop
     void resolve_events();               // after a stream sync
     int fail(int code, const std::string &msg) { last_error = msg; return code; }
@@ -121,7 +121,8 @@ struct Batch {
         bool valid = false; unsigned epoch = 0;
         void *h = nullptr, *d = nullptr; size_t bytes = 0;
         size_t o_req = 0, o_ops = 0, o_runs = 0, o_red = 0, nreq = 0, nruns = 0, neval = 0;
-        int max_mpad = 0; double algo_bytes = 0; bool any_pitch = false, any_chain = false;
+        int max_mpad = 0; double algo_bytes = 0, algo_flops = 0; bool any_pitch = false, any_chain = false;
+        bool stored = false;                       // recorded with every CLV written (the traversal a search runs) instead of OPF_NO_STORE
         std::vector<ReqSrc> src; std::vector<std::pair<int, int>> outs;
         std::vector<unsigned> rates_seen;          // per gene: rates_epoch the descriptors carry
     } plan;
@@ -132,7 +133,7 @@ struct Batch {
     unsigned topo_epoch = 0;       // bumped whenever a search may change a topology
     bool score_only_batch = false;
     int replay_plan(double *lnl);
-    bool record_plan = false;
+    bool record_plan = false, record_stored = false;
     std::vector<ReqSrc> last_src;
     std::vector<size_t> req_off; std::vector<uint32_t> req_stamp; std::vector<const double *> req_ptr; uint32_t req_launch = 0;   // run(): keyed request table
     std::vector<std::vector<int>> run_tails_of;
@@ -145,7 +146,7 @@ struct Batch {
     double *d_chain = nullptr, *h_chain = nullptr; size_t chain_cap = 0;     // 4 doubles per chained Newton result
     // a step of a chained pass whose upload + launches are issued later, grouped with its neighbours (flush_deferred)
     struct Deferred { size_t base, bytes, o_req, o_ops, o_runs, o_red, o_newt, nreq, nruns, neval, nnewton;
-                      int max_mpad, newton_maxm, lane; bool any_pitch, any_chain, stagger; double algo_bytes, newton_bytes; };
+                      int max_mpad, newton_maxm, lane; bool any_pitch, any_chain, stagger; double algo_bytes, newton_bytes, algo_flops; };
     std::vector<Deferred> deferred; size_t flush_quota = 1; bool lanes_active = false;
     int flush_deferred();
     int chain_begin(size_t nresults);
@@ -169,7 +170,9 @@ struct Batch {
     void branch_changed(int g, int a, int b);
     // lnL of every active gene at the branch above taxon 0, using/refreshing cached CLVs
     int evaluate(const std::vector<char> &active, double *lnl);
-    int score(const std::vector<char> &active, double *lnl);      // invalidate + evaluate
+    // invalidate + evaluate; stored: the whole-tree pass writes every CLV (chained children are still READ from registers),
+    // i.e. the traversal a search runs after a topology or alpha change -- bench.py's second timed leg
+    int score(const std::vector<char> &active, double *lnl, bool stored = false);
     int site_lnl(int g, double *out);
     int root_derivs(double *lnl, double *d1, double *d2);
     // one pass over the DIRTY branches (DFS order); a branch that moves by more than thr flags itself and

@@ -44,6 +44,19 @@ bool concatenate(int ngenes, const pml_alignment *genes, const std::vector<int> 
     }
     return true;
 }
+// replicate r = `subset` genes drawn without replacement (partial Fisher-Yates on one mt19937_64 stream), sorted
+std::vector<std::vector<int>> draw_subsets(int ngenes, int reps, int subset, unsigned long long seed) {
+    std::mt19937_64 rng(seed);
+    std::vector<std::vector<int>> rep((size_t)reps);
+    std::vector<int> all(ngenes); for (int i = 0; i < ngenes; ++i) all[i] = i;
+    for (int r = 0; r < reps; ++r) {
+        std::vector<int> pool(all);
+        for (int i = 0; i < subset; ++i) { const size_t j = i + (size_t)(rng() % (uint64_t)(ngenes - i)); std::swap(pool[i], pool[j]); }
+        rep[r].assign(pool.begin(), pool.begin() + subset);
+        std::sort(rep[r].begin(), rep[r].end());
+    }
+    return rep;
+}
 char *dup_cstr(const std::string &s) { char *p = (char *)std::malloc(s.size() + 1); if (p) std::memcpy(p, s.c_str(), s.size() + 1); return p; }
 }  // namespace
 
@@ -60,6 +73,48 @@ extern "C" int pml_concatenate(int ngenes, const pml_alignment *genes, int nsel,
         *fasta_out = dup_cstr(txt);
     } catch (const std::exception &) { return PML_ENOMEM; }
     return *fasta_out ? PML_OK : PML_ENOMEM;
+}
+
+extern "C" int pml_jackknife_draw(int ngenes, int reps, int subset_size, unsigned long long seed, int *sel_out) {
+    if (ngenes <= 0 || reps < 0 || !sel_out) return PML_EINVAL;
+    int subset = subset_size > 0 ? subset_size : ngenes / 2;
+    subset = std::max(1, std::min(subset, ngenes));
+    try {
+        const auto rep = draw_subsets(ngenes, reps, subset, seed);
+        for (int r = 0; r < reps; ++r) std::copy(rep[r].begin(), rep[r].end(), sel_out + (size_t)r * subset);
+    } catch (const std::exception &) { return PML_ENOMEM; }
+    return subset;
+}
+
+// Test hook for SURVEY 8f-3: the code matrix + weights k_gather builds on the device for one gene selection, read back.
+extern "C" int pml_debug_gather(pml_ctx *ctx, int ngenes, const pml_alignment *genes, int nsel, const int *sel,
+                                int *ntax_out, int *npat_out, int *mpad_out, unsigned char **codes_out, double **weights_out,
+                                char **names_out) {
+    if (!ctx || !genes || ngenes <= 0 || !ntax_out || !npat_out || !mpad_out || !codes_out || !weights_out || !names_out) return PML_EINVAL;
+    *codes_out = nullptr; *weights_out = nullptr; *names_out = nullptr;
+    std::lock_guard<std::mutex> lk(ctx->c.mu);
+    try {
+        for (int g = 0; g < ngenes; ++g) if (!genes[g].names || !genes[g].rows || genes[g].ntax <= 0) return ctx->c.fail(PML_EINVAL, "bad alignment");
+        std::vector<int> s;
+        if (sel) s.assign(sel, sel + nsel); else { s.resize(ngenes); for (int i = 0; i < ngenes; ++i) s[i] = i; }
+        GeneStore store;
+        struct Drop { GeneStore &s; ~Drop() { s.destroy(); } } drop{store};
+        if (int rc = store.create(&ctx->c, ngenes, reinterpret_cast<const pml_alignment_view *>(genes))) return rc;
+        Batch b;
+        struct DropB { Batch &b; ~DropB() { b.destroy(); } } dropb{b};
+        if (int rc = b.create_replicates(&ctx->c, store, {s}, 0, 4, 1.0)) return rc;
+        const Gene &G = b.genes[0];
+        const size_t nt = (size_t)G.aln.ntax, mp = (size_t)G.aln.mpad;
+        unsigned char *codes = (unsigned char *)std::malloc(nt * mp); double *w = (double *)std::malloc(mp * sizeof(double));
+        if (!codes || !w) { std::free(codes); std::free(w); return ctx->c.fail(PML_ENOMEM, "host allocation failed"); }
+        if (hipMemcpy(codes, G.d_codes, nt * mp, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(w, G.d_weight, mp * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+            std::free(codes); std::free(w); return ctx->c.fail(PML_EDEVICE, "read-back of the gathered matrix failed");
+        }
+        std::string names; for (auto &n : G.aln.names) { names += n; names += '\n'; }
+        *ntax_out = (int)nt; *npat_out = G.aln.npat; *mpad_out = (int)mp; *codes_out = codes; *weights_out = w; *names_out = dup_cstr(names);
+    } catch (const std::bad_alloc &) { return ctx->c.fail(PML_ENOMEM, "host allocation failed"); }
+    catch (const std::exception &e) { return ctx->c.fail(PML_EINVAL, e.what()); }
+    return PML_OK;
 }
 
 extern "C" int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *genes, const pml_model *model,
@@ -87,14 +142,7 @@ extern "C" int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *gene
         static_assert(sizeof(pml_alignment) == sizeof(pml_alignment_view), "alignment view layout");
         if (int rc = store.create(&ctx->c, ngenes, reinterpret_cast<const pml_alignment_view *>(genes))) return rc;
         // replicates: seeded draw without replacement (reference: RandomSetUtils.getRandomSet, unseeded)
-        std::mt19937_64 rng(opts ? opts->seed : 0);
-        std::vector<std::vector<int>> rep((size_t)reps);
-        for (int r = 0; r < reps; ++r) {
-            std::vector<int> pool(all);
-            for (int i = 0; i < subset; ++i) { const size_t j = i + (size_t)(rng() % (uint64_t)(ngenes - i)); std::swap(pool[i], pool[j]); }
-            rep[r].assign(pool.begin(), pool.begin() + subset);
-            std::sort(rep[r].begin(), rep[r].end());
-        }
+        std::vector<std::vector<int>> rep = draw_subsets(ngenes, reps, subset, opts ? opts->seed : 0);
         if (sworld > 1) {                       // this rank's replicates (all ranks drew the same lists)
             std::vector<std::vector<int>> mine;
             for (int r = srank; r < reps; r += sworld) mine.push_back(rep[r]);

@@ -1006,7 +1006,9 @@ void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad
     if (v == 11) {
         lds = (size_t)6 * PFRAG * sizeof(double) + 512;      // 77.3 KB: two workgroups per CU, which is what its 256 VGPRs allow anyway
         static const hipError_t big11 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_oplist<11>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)big11;
+        if (big11 != hipSuccess) {                           // no 77 KB of dynamic LDS: the single-buffered chained variant (25.6-38.4 KB) does the same work
+            v = 9; lds = (size_t)(2 + (any_pitch ? 1 : 0)) * PFRAG * sizeof(double) + 512;
+        }
     }
     const int ap = any_pitch ? 1 : 0;
     switch (v) {

@@ -64,11 +64,13 @@ def gather_results(gene_ids, lnl, alpha=None, tree_length=None, newicks=None, ne
     n = len(gene_ids)
     enc = [(s or "").encode() for s in newicks] if newicks is not None else None
     if enc is not None:
-        longest = max([len(b) for b in enc], default=0)
+        # the longest Newick over ALL ranks, always: with an explicit size every rank learns of a string that does not
+        # fit and raises together, before the collective (one rank raising alone would leave the others in the gather)
+        longest = _world_max(max([len(b) for b in enc], default=0))
         if not newick_bytes:
-            newick_bytes = (_world_max(longest) + 1 + 7) // 8 * 8
+            newick_bytes = (longest + 1 + 7) // 8 * 8
         elif longest > newick_bytes:
-            raise ValueError("gather_results: a %d-byte Newick does not fit newick_bytes=%d" % (longest, newick_bytes))
+            raise ValueError("gather_results: a %d-byte Newick (longest over all ranks) does not fit newick_bytes=%d" % (longest, newick_bytes))
     else:
         newick_bytes = 0
     width = RECORD_HEADER + (newick_bytes + 7) // 8
@@ -128,7 +130,8 @@ def jackknife(ctx, genes, reps=100, seed=0, newick_bytes=None, **kw):
     per = (reps + world - 1) // world
     nmine = len(range(rank, reps, world))
     ids = [rank + world * i if i < nmine else -1 for i in range(per)]
-    st = [(-5 if err is not None else 0) if i < nmine else 0 for i in range(per)]
+    # a replicate the engine returned no tree for (without raising) is a failed record, never an empty Newick counted as a tree
+    st = [(-5 if (err is not None or i >= len(mine) or not mine[i]) else 0) if i < nmine else 0 for i in range(per)]
     recs = gather_results(ids, np.zeros(per), newicks=(mine + [""] * per)[:per], newick_bytes=newick_bytes, status=st)
     if err is not None:
         raise err

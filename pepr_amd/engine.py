@@ -231,6 +231,27 @@ class Context:
             self.L.pml_free(sup)
         return out
 
+    def debug_gather(self, genes, sel=None):
+        """Test hook: the replicate code matrix k_gather builds on the device for the gene selection,
+        read back -> (names, codes uint8[ntax, npat], weights float64[npat])."""
+        import numpy as np
+        keep = []
+        n = len(genes)
+        alns = (_lib.Alignment * n)(*[_aln_struct(g[0], g[1], keep) for g in genes])
+        nt, npat, mpad = C.c_int(), C.c_int(), C.c_int()
+        codes, w, names = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        arr = (C.c_int * len(sel))(*sel) if sel is not None else None
+        rc = self.L.pml_debug_gather(self.ptr, n, alns, len(sel) if sel is not None else 0, arr, C.byref(nt), C.byref(npat),
+                                     C.byref(mpad), C.byref(codes), C.byref(w), C.byref(names))
+        self._check(rc)
+        cm = np.frombuffer(C.string_at(codes, nt.value * mpad.value), dtype=np.uint8).reshape(nt.value, mpad.value).copy()
+        wv = np.frombuffer(C.string_at(w, 8 * mpad.value), dtype=np.float64).copy()
+        nm = C.string_at(names).decode().splitlines()
+        for p in (codes, w, names):
+            self.L.pml_free(p)
+        assert np.all(wv[npat.value:] == 0) and np.all(cm[:, npat.value:] == 22), "padding patterns must be weightless gaps"
+        return nm, cm[:, :npat.value], wv[:npat.value]
+
     # ---- single-gene calls (what one Java thread issues); concurrent ones are coalesced inside the library ----
     def _single(self, fn, gene, newick, model, extra):
         keep = []
@@ -267,7 +288,9 @@ class Context:
         for name, k in KERNELS.items():
             n, ms, by = C.c_longlong(), C.c_double(), C.c_double()
             self._check(self.L.pml_kernel_stats(self.ptr, k, C.byref(n), C.byref(ms), C.byref(by)))
-            out[name] = {"launches": n.value, "ms": ms.value, "algo_bytes": by.value}
+            fl = C.c_double()
+            self._check(self.L.pml_kernel_flops(self.ptr, k, C.byref(fl)))
+            out[name] = {"launches": n.value, "ms": ms.value, "algo_bytes": by.value, "algo_flops": fl.value}
         if reset:
             self.L.pml_kernel_stats_reset(self.ptr)
         return out
@@ -303,9 +326,11 @@ class Batch:
     def npatterns(self):
         return [self.L.pml_batch_npatterns(self.ptr, g) for g in range(self.n)]
 
-    def score(self):
+    def score(self, stored=False):
+        """full post-order pass + root evaluation of every gene; stored=True writes every CLV (the traversal a search runs)"""
         out = np.zeros(self.n)
-        self.ctx._check(self.L.pml_batch_score(self.ptr, out.ctypes.data_as(C.POINTER(C.c_double))))
+        fn = self.L.pml_batch_score_stored if stored else self.L.pml_batch_score
+        self.ctx._check(fn(self.ptr, out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
     def site_lnl(self, g, nsites):
@@ -394,6 +419,19 @@ def support_tree(main_newick, support_newicks, digits=6):
     s = C.string_at(p).decode()
     L.pml_free(p)
     return s
+
+
+def jackknife_draw(ngenes, reps, subset_size=0, seed=0):
+    """The gene subsets pml_jackknife draws (host only): list of `reps` ascending index lists."""
+    L = _lib.load()
+    k = subset_size if subset_size > 0 else max(1, ngenes // 2)
+    k = max(1, min(k, ngenes))
+    out = (C.c_int * (reps * k))()
+    rc = L.pml_jackknife_draw(ngenes, reps, subset_size, seed, out)
+    if rc < 0:
+        raise PmlError(rc)
+    assert rc == k
+    return [list(out[r * k:(r + 1) * k]) for r in range(reps)]
 
 
 def concatenate(genes, sel=None):

@@ -17,6 +17,8 @@ def main():
     b = engine.Batch(ctx, A, T, alpha=0.8)
     out["score"] = [float(x).hex() for x in b.score()]
     out["score_again"] = [float(x).hex() for x in b.score()]
+    out["score_stored"] = [float(x).hex() for x in b.score(stored=True)]        # every CLV written (bench.py's second leg)
+    out["score_stored_replay"] = [float(x).hex() for x in b.score(stored=True)]
     lnl, al = b.optimize()             # after a scoring pass that kept its chained results in registers only
     out["batch_optimize"] = [float(x).hex() for x in lnl] + [float(x).hex() for x in al]
     b.close()

@@ -154,11 +154,20 @@ import pytest as _pytest
 def test_bench_two_ranks_on_one_gpu():
     """the real N = 2 path end to end: bench.py starts its own two ranks, both drive the one GPU of the test box
     (BENCH_FORCE_DEVICE=0) and talk over gloo; weak and strong scaling"""
-    env = {"BENCH_BACKEND": "gloo", "BENCH_FORCE_DEVICE": "0"}
-    rc, out, err = _run_bench(["--gpus", "2", "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env)
+    import torch
+    # two visible devices: one rank per GPU over RCCL (the `nccl` branch of pepr_amd/distributed.py); the one-GPU test box:
+    # both ranks on device 0 over gloo
+    env = {} if torch.cuda.device_count() >= 2 else {"BENCH_BACKEND": "gloo", "BENCH_FORCE_DEVICE": "0"}
+    # BENCH_FORCE_C4 + a small shape: the c4_strong record of the N > 1 line (the 500-gene job dealt by cost, one gather) in miniature
+    env_c4 = dict(env, BENCH_FORCE_C4="1", BENCH_C4_GENES="7", BENCH_C4_SHAPE="14,260")
+    rc, out, err = _run_bench(["--gpus", "2", "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env_c4)
     assert rc == 0, err[-2000:]
     assert len(out) == 1 and out[0]["n_gpus"] == 2 and out[0]["scaling"] == "weak" and out[0]["config"]["genes_total"] == 16
     assert out[0]["search"]["genes"] == 16 and out[0]["search"]["finite"]
+    assert 0 < out[0]["roofline"]["frac"] < 1 and out[0]["stored_traversal"]["value"] > 0 and out[0]["cold"]["value"] > 0
+    c4 = out[0]["c4_strong"]
+    assert c4["search_nni"]["records_gathered"] == 7 and c4["search_nni_spr5"]["records_gathered"] == 7 and c4["score"]["value"] > 0
+    assert c4["search_nni"]["rank_seconds_max"] >= c4["search_nni"]["rank_seconds_min"] > 0
     rc, out, err = _run_bench(["--gpus", "2", "--workload", "tiny", "--scaling", "strong", "--genes", "11", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env)
     assert rc == 0, err[-2000:]
     assert out[0]["n_gpus"] == 2 and out[0]["scaling"] == "strong" and out[0]["config"]["genes_total"] == 11 and out[0]["search"]["genes"] == 11

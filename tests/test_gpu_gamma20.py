@@ -35,6 +35,16 @@ def test_gamma20_batch_is_composition_independent(gpu_ctx):
         assert one["lnl"] == whole[i]["lnl"] and one["alpha"] == whole[i]["alpha"] and one["rescale"] == whole[i]["rescale"]
 
 
+def test_gamma20_batch_sub_batches_under_an_hbm_budget(gpu_ctx, monkeypatch):
+    """a gene list that does not fit in HBM at once is fitted in consecutive sub-batches (as pml_search_batch does): same bits"""
+    genes = [synth.simulate_alignment(12, 200, 400 + i, 0.8) for i in range(6)]
+    G = [(g[0], g[1]) for g in genes]; NW = [g[2] for g in genes]
+    whole = gpu_ctx.gamma20(G, NW)
+    monkeypatch.setenv("PML_HBM_BUDGET_MB", "5")          # one 12 x 200 gene needs ~3.6 MB: one or two genes per sub-batch
+    parts = gpu_ctx.gamma20(G, NW)
+    assert [(p["lnl"], p["alpha"], p["rescale"], p["newick"]) for p in parts] == [(w["lnl"], w["alpha"], w["rescale"], w["newick"]) for w in whole]
+
+
 def test_gamma20_recovers_a_known_rescale(gpu_ctx):
     """the same data scored on a tree whose lengths were all shrunk by 1.25: the fitted rescale grows by that factor and the
     Gamma20 likelihood barely moves (the continuous model is invariant under lengths / c, mean rate x c; the FIXED 20-rate grid

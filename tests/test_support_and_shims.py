@@ -109,3 +109,16 @@ def test_raxml_shim_f_b_draws_bipartitions(tmp_path):
     out = (tmp_path / "RAxML_bipartitions.b1").read_text().strip()
     assert sorted(int(x) for x in re.findall(r"\)(\d+):", out)) == [25, 75]        # (c,d) in 1 of 4, (a,b) in 3 of 4
     assert out.endswith(":0.0;")
+
+
+def test_jackknife_draw_host_only():
+    """pml_jackknife_draw (RandomSetUtils.java:9-35 restated with a seed): subsets without replacement, ascending,
+    deterministic per seed, half the genes by default (PhylogenomicPipeline2.java:1599-1617)."""
+    from pepr_amd import engine
+    d = engine.jackknife_draw(11, 40, 0, 7)
+    assert len(d) == 40 and all(len(s) == 5 and s == sorted(set(s)) and 0 <= s[0] and s[-1] < 11 for s in d)
+    assert d == engine.jackknife_draw(11, 40, 0, 7) and d != engine.jackknife_draw(11, 40, 0, 8)
+    assert len({tuple(s) for s in d}) > 20                      # genuinely different subsets
+    assert engine.jackknife_draw(4, 3, 9, 1) == [[0, 1, 2, 3]] * 3   # subset larger than the gene list = all genes
+    counts = [sum(g in s for s in engine.jackknife_draw(10, 2000, 0, 3)) for g in range(10)]
+    assert min(counts) > 850 and max(counts) < 1150             # every gene drawn about half the time
