@@ -168,9 +168,16 @@ def plumbing_only(world_expected):
 
 
 def git_head():
+    """commit of the build: git when the checkout is here, else the stamp __graft_entry__.build() left (.git does not travel to the GPU box)"""
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
-    except Exception:       # noqa: BLE001 -- no git on the GPU box's copy (.git does not travel)
+        h = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+        if h:
+            return h
+    except Exception:       # noqa: BLE001
+        pass
+    try:
+        return open(os.path.join(ROOT, "pepr_amd", "BUILD_COMMIT")).read().strip() or None
+    except OSError:
         return None
 
 

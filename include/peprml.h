@@ -243,6 +243,14 @@ int pml_concatenate(int ngenes, const pml_alignment *genes, int nsel, const int 
  * coalesced into device batches; this reports how many batches ran and how many single calls they carried. */
 int pml_coalescing_stats(pml_ctx *ctx, long long *batches, long long *requests);
 
+/* The branch-length Newton kernel splits a request over several workgroups that exchange partial sums.  Its forward progress
+ * does not depend on dispatch order (slices are claimed by ticket), and its waits are bounded in wall-clock time: when a wait
+ * gives up (a co-tenant of the GPU kept a request's slices apart for > 2 s), the affected requests -- in a chained smoothing
+ * pass, the whole pass -- are re-issued through a no-exchange form of the same kernel whose results are bit-identical, and the
+ * call succeeds.  This reports how often that happened on the context: give-up events, requests re-issued, launches of the
+ * no-exchange form (all 0 on a GPU the process has to itself). */
+int pml_newton_fallbacks(pml_ctx *ctx, long long *giveups, long long *reissued, long long *seq_launches);
+
 /* Every computing entry point runs its host-side arithmetic under the DEFAULT floating-point control state (round to
  * nearest, no flush-to-zero / denormals-are-zero) whatever the calling thread -- a JVM worker, a Python thread -- came in
  * with, and restores the caller's state on return: results do not depend on the caller's MXCSR.  Diagnostic: the distinct

@@ -18,7 +18,7 @@ SYMBOLS = [
     "pml_batch_create", "pml_batch_destroy", "pml_batch_size", "pml_batch_npatterns",
     "pml_batch_score", "pml_batch_score_stored", "pml_batch_site_lnl", "pml_batch_set_alpha", "pml_batch_optimize",
     "pml_batch_search", "pml_batch_newick", "pml_batch_root_derivs", "pml_free",
-    "pml_rf_distance", "pml_support_tree", "pml_jackknife", "pml_jackknife_draw", "pml_debug_gather", "pml_concatenate", "pml_parsimony", "pml_parsimony_batch", "pml_refine_next", "pml_bootstrap", "pml_coalescing_stats", "pml_sh_support", "pml_sh_support_batch", "pml_gamma20", "pml_gamma20_batch", "pml_debug_fpenv", "pml_kernel_stats", "pml_kernel_flops", "pml_kernel_stats_reset",
+    "pml_rf_distance", "pml_support_tree", "pml_jackknife", "pml_jackknife_draw", "pml_debug_gather", "pml_concatenate", "pml_parsimony", "pml_parsimony_batch", "pml_refine_next", "pml_bootstrap", "pml_coalescing_stats", "pml_newton_fallbacks", "pml_sh_support", "pml_sh_support_batch", "pml_gamma20", "pml_gamma20_batch", "pml_debug_fpenv", "pml_kernel_stats", "pml_kernel_flops", "pml_kernel_stats_reset",
 ]
 
 
@@ -122,6 +122,7 @@ def load():
     L.pml_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_longlong), dp, dp]
     L.pml_kernel_flops.argtypes = [vp, C.c_int, dp]
     L.pml_kernel_stats_reset.argtypes = [vp]
+    L.pml_newton_fallbacks.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.pml_coalescing_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     _lib = L
     return L

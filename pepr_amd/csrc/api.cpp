@@ -580,6 +580,14 @@ int pml_kernel_stats(pml_ctx *ctx, int k, long long *launches, double *ms, doubl
     if (bytes) *bytes = ctx->c.stats[k].bytes;
     return PML_OK;
 }
+int pml_newton_fallbacks(pml_ctx *ctx, long long *giveups, long long *reissued, long long *seq_launches) {
+    if (!ctx) return PML_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->c.mu);
+    if (giveups) *giveups = ctx->c.newton_giveups;
+    if (reissued) *reissued = ctx->c.newton_reissued;
+    if (seq_launches) *seq_launches = ctx->c.newton_seq_launches;
+    return PML_OK;
+}
 int pml_kernel_flops(pml_ctx *ctx, int k, double *flops) {
     if (!ctx || !flops || k < 0 || k >= K_COUNT) return PML_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->c.mu);

@@ -245,6 +245,7 @@ void Batch::destroy() {
     if (d_stage) hipFree(d_stage);
     if (d_frags) hipFree(d_frags);
     if (d_nsync) hipFree(d_nsync);
+    if (d_nctl) { hipFree(d_nctl); d_nctl = nullptr; }
     if (ev_stagger) { hipEventDestroy(ev_stagger); ev_stagger = nullptr; }
     if (d_nsync2) hipFree(d_nsync2);
     if (d_frags2) hipFree(d_frags2);
@@ -560,6 +561,19 @@ static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+void Batch::newton_gave_up() {
+    ++ctx->newton_giveups;
+    safe_left = safe_hold; safe_hold = std::min(safe_hold * 2, 1024);
+}
+// the sticky abort word of both lanes' control blocks back to 0 (ordered on the batch's streams, then waited for)
+int Batch::clear_abort() {
+    if (!d_nctl) return 0;
+    for (int l = 0; l < 2; ++l) HIPCHK(hipMemsetAsync(&d_nctl[l].abort, 0, sizeof(int), l ? ctx->stream2 : ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream2));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 // one upload for all deferred steps (their descriptors are consecutive in the staging ring), then their launches in order
 int Batch::flush_deferred() {
     if (deferred.empty()) return 0;
@@ -596,7 +610,8 @@ int Batch::flush_deferred() {
         }
         if (L.nnewton) {
             ctx->tic(K_NEWTON, L.newton_bytes);
-            launch_newton(md, (const NewtonReq *)(ds + L.o_newt), (int)L.nnewton, L.newton_maxm, st);
+            if (L.seq) { launch_newton_seq(md, (const NewtonReq *)(ds + L.o_newt), (const int *)(ds + L.o_tick), L.nt_reg, L.nt_stream, d_nctl + L.lane, st); ++ctx->newton_seq_launches; }
+            else launch_newton(md, (const NewtonReq *)(ds + L.o_newt), (const int *)(ds + L.o_tick), L.nt_reg, L.nt_stream, d_nctl + L.lane, st);
             ctx->toc(); PML_SER();
         }
         ctx->tic_stream = nullptr;
@@ -640,6 +655,10 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         HIPCHK(hipMalloc((void **)&nsync_buf, cap * NEWTON_SYNC_DOUBLES * sizeof(double)));
         nsync_c = cap;
     }
+    if (nnewton && !d_nctl) {
+        HIPCHK(hipMalloc((void **)&d_nctl, 2 * sizeof(NewtonCtl)));
+        HIPCHK(hipMemset(d_nctl, 0, 2 * sizeof(NewtonCtl)));
+    }
     const hipStream_t st = lane ? ctx->stream2 : ctx->stream;
     double *const frags_buf = lane ? d_frags2 : d_frags;
     ctx->tic_stream = st;
@@ -649,7 +668,10 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     const size_t o_runs = align_up(o_ops + (nops + ntail) * sizeof(NvOp), 256);
     const size_t o_red = align_up(o_runs + ngenes * sizeof(GeneRun), 256);
     const size_t o_newt = align_up(o_red + neval * sizeof(ReduceReq), 256);
-    const size_t bytes = align_up(o_newt + nnewton * sizeof(NewtonReq), 256);
+    size_t ntick_max = 0;                          // k_newton tickets: one per (request, slice)
+    for (auto &t : tails) if (t.mode == MODE_SUMTABLE) ntick_max += (size_t)newton_split(genes[t.gene].aln.mpad);
+    const size_t o_tick = align_up(o_newt + nnewton * sizeof(NewtonReq), 256);
+    const size_t bytes = align_up(o_tick + ntick_max * sizeof(int), 256);
     if (chain && chain_off + bytes > h_cap) { if (int rc = chain_sync()) return rc; }     // ring full: drain, start over
     if (int rc = ensure_stage(bytes)) return rc;
     const size_t base = chain ? chain_off : 0;
@@ -660,6 +682,8 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     GeneRun *hruns = (GeneRun *)(hs + o_runs);
     ReduceReq *hred = (ReduceReq *)(hs + o_red);
     NewtonReq *hnewt = (NewtonReq *)(hs + o_newt);
+    int *htick = (int *)(hs + o_tick);
+    std::vector<int> tail_req(ntail, -1);          // tail -> index of its NewtonReq (failure handling below)
     const double *eig = ctx->d_eigfrags[pi_mode];
 
     size_t nout = 0, nruns = 0, ie = 0, in = 0, ireq = 0, iop = 0;
@@ -827,6 +851,8 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
                 d.out = stab; d.out_scl = sscl;
                 d.aux = nsync_buf + (size_t)in * NEWTON_SYNC_DOUBLES;
                 NewtonReq &nr = hnewt[in];
+                tail_req[&t - tails.data()] = (int)in;
+                nr.ticket0 = 0; nr.pad = 0;
                 nr.sumtab = stab; nr.weight = G.d_weight; nr.scl = sscl;
                 std::memcpy(nr.rates, G.rates, sizeof nr.rates);
                 nr.t0 = t.t0; nr.tol = newton_tol; nr.out = result; nr.mpad = mp; nr.max_iter = t.max_iter;
@@ -907,10 +933,28 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     }
 
     if (req_overflow) return ctx->fail(-5, "internal: transition-matrix request bound exceeded");
+    // k_newton's ticket table: (request, slice) in request order, register-form requests first, then the streaming-form ones
+    // (genes of more than 8192 patterns); in safe mode (SEQ form) one entry per request instead
+    int nt_reg = 0, nt_stream = 0;
+    const bool seq_launch = nnewton > 0 && newton_safe_mode();
+    {
+        int cur = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            for (size_t i = 0; i < nnewton; ++i) {
+                if (newton_reg_form(hnewt[i].mpad) != (pass == 0)) continue;
+                const int S = seq_launch ? 1 : newton_split(hnewt[i].mpad);
+                hnewt[i].ticket0 = cur - (pass == 0 ? 0 : nt_reg);            // relative to its kernel's table
+                for (int k = 0; k < S; ++k) htick[cur++] = (int)i;
+            }
+            if (pass == 0) nt_reg = cur; else nt_stream = cur - nt_reg;
+        }
+        if (nnewton && safe_left > 0 && !safe_now) --safe_left;
+    }
     double newton_bytes = 0;
     for (auto &t : tails) if (t.mode < MODE_EVALUATE) newton_bytes += (double)genes[t.gene].aln.npat * 640;
     Deferred L;
     L.base = base; L.bytes = bytes; L.o_req = o_req; L.o_ops = o_ops; L.o_runs = o_runs; L.o_red = o_red; L.o_newt = o_newt;
+    L.o_tick = o_tick; L.nt_reg = nt_reg; L.nt_stream = nt_stream; L.seq = seq_launch;
     L.nreq = ireq; L.nruns = nruns; L.neval = neval; L.nnewton = nnewton; L.max_mpad = max_mpad; L.newton_maxm = newton_maxm;
     L.any_pitch = any_pitch; L.any_chain = any_chain; L.algo_bytes = algo_bytes; L.algo_flops = algo_flops; L.newton_bytes = newton_bytes; L.lane = lane; L.stagger = record_stagger;
     record_stagger = false;
@@ -934,13 +978,34 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += t_done - t_launched;
         host_phase_ms[HP_RUN_SYNCED] += t_launched - t_begin;           // descriptor build of a launch the device waited for
         ctx->resolve_events();
-        // a Newton request whose cross-workgroup exchange timed out reports lnL = NaN (k_newton): that is a device
-        // failure, never a result
+        // A Newton request whose cross-workgroup exchange gave up reports lnL = NaN (k_newton).  Its sumtable is still in
+        // place: the affected requests are re-issued through the no-exchange SEQ form (one workgroup walks the slices; the
+        // bits of the split form), here, before anybody consumes a result.
+        auto result_of = [&](const Tail &t) { return t.result_host ? t.result_host : (t.result_dev ? (const double *)nullptr : res(t.gene, t.slot)); };
+        std::vector<int> bad;
+        for (size_t i = 0; i < ntail; ++i) {
+            const Tail &t = tails[i];
+            if (t.mode != MODE_SUMTABLE) continue;
+            const double *h = result_of(t);
+            if (h && !std::isfinite(h[1])) bad.push_back(tail_req[i]);
+        }
+        if (!bad.empty() && !seq_launch) {
+            newton_gave_up(); ctx->newton_reissued += (long long)bad.size();
+            int nr = 0, ns = 0;
+            for (int pass = 0; pass < 2; ++pass) for (int i : bad) if (newton_reg_form(hnewt[i].mpad) == (pass == 0)) { htick[nr + ns] = i; ++(pass == 0 ? nr : ns); }
+            if (int rc = clear_abort()) return rc;
+            HIPCHK(hipMemcpyAsync(ds + o_tick, hs + o_tick, bad.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            launch_newton_seq(ctx->d_model[pi_mode], (const NewtonReq *)(ds + o_newt), (const int *)(ds + o_tick), nr, ns, d_nctl + lane, ctx->stream);
+            ++ctx->newton_seq_launches;
+            if (int rc = fetch_results(pooled)) return rc;
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            HIPCHK(hipGetLastError());
+        }
         for (auto &t : tails) {
             if (t.mode == MODE_EVALUATE_CAT) continue;
-            const double *h = t.result_host ? t.result_host : (t.result_dev ? nullptr : res(t.gene, t.slot));
+            const double *h = result_of(t);
             if (h && !std::isfinite(t.mode == MODE_EVALUATE ? h[0] : h[1]))
-                return ctx->fail(-5, t.mode == MODE_EVALUATE ? "device returned a non-finite likelihood" : "k_newton: cross-workgroup exchange timed out (non-finite result); is another process using this GPU? the engine needs the device to itself");
+                return ctx->fail(-5, t.mode == MODE_EVALUATE ? "device returned a non-finite likelihood" : "k_newton: non-finite branch likelihood (also from the no-exchange form)");
         }
     }
     for (auto &o : ops) if (o.out_kind == SIDE_MSG) { Gene &G = genes[o.gene]; G.valid[o.out_id] = o.unstored ? 0 : 1; G.pend_level[o.out_id] = -1; }
@@ -1072,6 +1137,7 @@ int Batch::root_derivs(double *lnl, double *d1, double *d2) {
 int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &maxdelta, double thr) {
     const int n = (int)genes.size();
     maxdelta.assign(n, 0.0);
+    struct SafeOff { bool &f; ~SafeOff() { f = false; } } safe_off{safe_now};     // whichever way the pass is left
     double hp_t = now_ms();
     // per-gene DFS edge order, restricted to dirty branches
     // (scratch kept between passes: this set-up runs while the device is idle)
@@ -1108,9 +1174,15 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
     // there (PmatReq::tp).  The host learns the new lengths after ONE synchronisation at the end of the pass.
     static const bool no_chain = std::getenv("PML_NO_CHAIN") != nullptr;
     size_t nres = 0; for (int g = 0; g < n; ++g) nres += order[g].size();
-    if (!no_chain) { if (int rc = chain_begin(nres)) return rc; }
     struct Done { int gene, v, w; double old; size_t idx; };
     std::vector<Done> done; done.reserve(nres);
+    // attempt 1 re-runs the WHOLE pass through the no-exchange Newton form when k_newton's exchange gave up somewhere in the
+    // chained attempt 0: the host's branch lengths are still those of the pass start (new lengths live on the device until the
+    // pass is accepted), the dirty flags are untouched, and CLVs computed from unaccepted lengths are invalidated -- so the
+    // second attempt computes exactly what an untroubled pass computes
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    done.clear();
+    if (!no_chain) { if (int rc = chain_begin(nres)) return rc; }
     auto fail_out = [&](int rc) { if (chain) { chain_sync(); chain = false; } return rc; };
     // two lanes: with enough genes the pass is issued as two independent halves (even / odd genes) on two streams.
     // One half's latency-bound stretches (k_newton's cross-workgroup exchanges, k_pmat, kernel boundaries) then
@@ -1180,8 +1252,16 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
         ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += now_ms() - t0;
         host_phase_ms[HP_PASS_SYNC] += now_ms() - t0; hp_t = now_ms();
         chain = false; lanes_active = false;
-        for (auto &d : done) if (!std::isfinite(h_chain[4 * d.idx + 1]))
-            return ctx->fail(-5, "k_newton: cross-workgroup exchange timed out (non-finite result); is another process using this GPU? the engine needs the device to itself");
+        bool gave_up = false;
+        for (auto &d : done) gave_up = gave_up || !std::isfinite(h_chain[4 * d.idx + 1]);
+        if (gave_up) {
+            if (attempt == 1 || safe_now) return ctx->fail(-5, "k_newton: non-finite branch likelihood (also from the no-exchange form)");
+            newton_gave_up(); ctx->newton_reissued += (long long)done.size();
+            if (int rc = clear_abort()) return rc;
+            for (int g = 0; g < n; ++g) if (active[g]) { std::fill(genes[g].len_pending.begin(), genes[g].len_pending.end(), 0); invalidate_all(g); }
+            safe_now = true;
+            continue;
+        }
         for (auto &d : done) {
             Gene &G = genes[d.gene];
             const double nl = h_chain[4 * d.idx], dl = std::fabs(nl - d.old);
@@ -1192,6 +1272,9 @@ int Batch::smooth_pass(const std::vector<char> &active, std::vector<double> &max
         }
         for (auto &G : genes) std::fill(G.len_pending.begin(), G.len_pending.end(), 0);
     }
+    break;
+    }   // attempts
+    safe_now = false;
     for (int g = 0; g < n; ++g) if (active[g]) genes[g].dirty.swap(next[g]);
     host_phase_ms[HP_PASS_POST] += now_ms() - hp_t;
     return 0;

@@ -27,6 +27,7 @@ struct Ctx {
     ModelDev *d_model[2] = {nullptr, nullptr};
     double *d_eigfrags[2] = {nullptr, nullptr};   // 2*PFRAG doubles each
     struct KStat { long long launches = 0; double ms = 0; double bytes = 0; double flops = 0; } stats[K_COUNT];
+    long long newton_giveups = 0, newton_reissued = 0, newton_seq_launches = 0;   // k_newton fallback statistics (pml_newton_fallbacks)
     struct Ev { int kind; hipEvent_t a, b; };
     std::vector<Ev> pending;
     std::vector<hipEvent_t> pool;
@@ -114,6 +115,14 @@ struct Batch {
     size_t scalars_doubles = 0, results_used = 0;
     int fetch_results(bool pooled);                              // enqueue the device -> host copies of the result buffers
     double *d_nsync = nullptr; size_t nsync_cap = 0;             // Newton inter-workgroup sync blocks
+    NewtonCtl *d_nctl = nullptr;                                  // [2]: k_newton control block per lane (tickets, abort word)
+    // k_newton's exchange gave up (a co-tenant kept slices of a request apart for longer than the wall-clock bound): the
+    // affected work is re-issued through the no-exchange SEQ form, and the next `safe_left` Newton launch sets use it from the
+    // start (doubling hold-off, so a GPU that stays shared costs one time-out per hold-off period, not one per launch)
+    int safe_left = 0, safe_hold = 4; bool safe_now = false;
+    bool newton_safe_mode() { return safe_now || safe_left > 0; }
+    void newton_gave_up();
+    int clear_abort();
     // cached descriptors of the full-traversal score of ALL genes (topology unchanged): replays skip
     // the tree walk and the descriptor build; transition matrices, CLVs and lnL are recomputed
     struct ReqSrc { int gene, v, q, fold; };      // branch (v, slot q) whose length a P request uses
@@ -145,7 +154,7 @@ struct Batch {
     double *d_lenpool = nullptr;
     double *d_chain = nullptr, *h_chain = nullptr; size_t chain_cap = 0;     // 4 doubles per chained Newton result
     // a step of a chained pass whose upload + launches are issued later, grouped with its neighbours (flush_deferred)
-    struct Deferred { size_t base, bytes, o_req, o_ops, o_runs, o_red, o_newt, nreq, nruns, neval, nnewton;
+    struct Deferred { size_t base, bytes, o_req, o_ops, o_runs, o_red, o_newt, o_tick, nreq, nruns, neval, nnewton; int nt_reg, nt_stream; bool seq;
                       int max_mpad, newton_maxm, lane; bool any_pitch, any_chain, stagger; double algo_bytes, newton_bytes, algo_flops; };
     std::vector<Deferred> deferred; size_t flush_quota = 1; bool lanes_active = false;
     int flush_deferred();

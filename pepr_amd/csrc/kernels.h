@@ -112,8 +112,19 @@ struct NewtonReq {          // Newton-Raphson on one branch from its sumtable
     double *patlnl;         // optional: per-pattern lnL (scaling applied) at the returned length, [mpad] (SH-like supports)
     int mpad;
     int max_iter;           // 0: derivatives at t0 only
+    int ticket0;            // first ticket of this request in its kernel's ticket table (k_newton: slice = ticket - ticket0)
+    int pad;
 };
 constexpr int NEWTON_MAX_SPLIT = 64;    // 128-pattern slices up to 8192 patterns stay register-resident (k_newton)
+// the split of a request over workgroups: a function of its pattern count alone (bit-reproducible whatever shares the launch)
+constexpr int NEWTON_SLICE_PAT = 128;
+__host__ __device__ constexpr int newton_split(int mpad) { return (mpad + NEWTON_SLICE_PAT - 1) / NEWTON_SLICE_PAT < NEWTON_MAX_SPLIT ? ((mpad + NEWTON_SLICE_PAT - 1) / NEWTON_SLICE_PAT < 1 ? 1 : (mpad + NEWTON_SLICE_PAT - 1) / NEWTON_SLICE_PAT) : NEWTON_MAX_SPLIT; }
+// register form: a slice IS a tile of the sumtable (80 KB contiguous); beyond 64 tiles the slices grow and stream
+__host__ __device__ constexpr int newton_slice(int mpad) { return mpad <= NEWTON_SLICE_PAT * NEWTON_MAX_SPLIT ? NEWTON_SLICE_PAT : ((mpad / 32 + newton_split(mpad) - 1) / newton_split(mpad)) * 32; }
+__host__ __device__ constexpr bool newton_reg_form(int mpad) { return newton_slice(mpad) <= NEWTON_SLICE_PAT; }
+// per (batch, stream) control block of k_newton, zeroed once at allocation: ticket / done counters of the register-form [0]
+// and streaming-form [1] kernels (the last workgroup of a launch re-arms them) and the sticky abort word the host clears
+struct NewtonCtl { int ticket[2]; int done[2]; int abort; int pad[3]; };
 constexpr int NEWTON_SYNC_DOUBLES = 2 * NEWTON_MAX_SPLIT * 6;   // two parities x slices x six 8-byte {tag, half a double} granules (three partial sums)
 
 // MODE_EVALUATE_CAT: like MODE_EVALUATE but the four categories are NOT averaged: out[c][p] = sum_s L_c[s] (pi P_c . R_c)[s]
@@ -157,6 +168,9 @@ void launch_eigfrags(const ModelDev *model, double *frags2, hipStream_t s);
 // any_pitch: some op has an SK_PITCH side (two more LDS fragment regions are allocated)
 void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, bool any_pitch, bool chained, hipStream_t s);
 void launch_reduce(const ReduceReq *reqs, int n, hipStream_t s);
-void launch_newton(const ModelDev *model, const NewtonReq *reqs, int n, int max_mpad, hipStream_t s);
+// tickets: request index per ticket, register-form tickets [0, nreg) then streaming-form [nreg, nreg + nstream)
+void launch_newton(const ModelDev *model, const NewtonReq *reqs, const int *tickets, int nreg, int nstream, NewtonCtl *ctl, hipStream_t s);
+// the no-exchange fallback: one workgroup per listed request (register-form requests first), same bits as the split form
+void launch_newton_seq(const ModelDev *model, const NewtonReq *reqs, const int *req_list, int nreg, int nstream, NewtonCtl *ctl, hipStream_t s);
 
 }  // namespace pml

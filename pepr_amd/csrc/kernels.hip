@@ -611,15 +611,28 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceReq *__restrict__ re
 // A granule is indivisible, so a consumer can never pair a tag with bytes of another evaluation;
 // no ordering between different words is needed (no flag, no fence, no s_waitcnt).  A slot is only
 // overwritten two evaluations later (parity double buffer), which its producer can reach only after
-// every consumer has finished the evaluation in between.  (Round 1 posted the sums and a separate
-// arrival tag ordered by s_waitcnt: a form measured only at one workgroup per CU; a consumer that saw
-// the tag before a sum is the likely cause of the last-bit difference once seen between a lone and
-// a coalesced call.)  The sums of all slices are combined in a fixed tree order that depends on S
-// alone, S depends on the request alone: bit-reproducible whatever else is in the launch.
-// Every workgroup of a request executes the same evaluations because all see identical sums.
-// Forward progress: workgroups are dispatched in grid order (x fastest), so the lowest unfinished
-// request always has its <= 64 slices resident or next in line; the spin is bounded anyway and a
-// timeout is REPORTED: lnL = NaN, which the host turns into PML_EDEVICE (engine.cpp check_newton).
+// every consumer has finished the evaluation in between.  The sums of all slices are combined in a
+// fixed tree order that depends on S alone, S depends on the request alone: bit-reproducible
+// whatever else is in the launch.  Every workgroup of a request executes the same evaluations
+// because all see identical sums.
+//
+// FORWARD PROGRESS (round 3; rounds 1-2 relied on workgroups being dispatched in grid order, which holds
+// for ONE queue of ONE process only: with co-tenants the XCDs fill with spinning slices of different
+// requests whose partners are bound for another, equally full XCD -- the recorded time-out of four
+// ranks on one GPU).  Slices are no longer tied to blockIdx: a workgroup that
+// STARTS takes the next ticket of the launch (one atomic add) and the ticket names (request, slice)
+// through a host-built table in request-major order.  Whoever holds ticket k is running, and so is
+// (or has finished) every holder of a ticket < k: all requests but the newest are fully staffed and
+// finish without waiting for anything that has not started; the newest waits only for workgroups the
+// dispatcher can place in ANY free slot on ANY XCD.  Waiting never depends on the order in which
+// the hardware dispatches, only on it dispatching at all.
+// Belt and braces: the wait is bounded in WALL-CLOCK time (s_memrealtime, 100 MHz); the first slice
+// that gives up raises the launch-wide abort word, which every spinning slice polls and every later
+// k_newton launch of the stream checks on entry, so the device drains at once instead of spinning
+// its bound per resident batch; affected requests report lnL = NaN and the host re-issues them
+// through k_newton<..., SEQ = true>: ONE workgroup walks the request's slices in turn through the
+// same per-slice code and combines the slice sums with the same shuffle tree -- no exchange, the
+// bits of the split form (engine.cpp: Batch::run / smooth_pass; tests/test_gpu_newton_fallback.py).
 // Control flow is the oracle's eng_newton_branch().
 // ------------------------------------------------------------------------------------------
 #define PML_TMIN 1.0e-6
@@ -643,14 +656,16 @@ constexpr int NEWTON_THREADS = 512;           // 8 waves, four lanes per pattern
 constexpr int NEWTON_WAVES = NEWTON_THREADS / 64;
 constexpr int NEWTON_SLICE = NEWTON_WAVES * 16;           // patterns per register-resident slice
 constexpr int NEWTON_ROWS = CLV_ROWS / 4;     // sumtable rows per lane (20 doubles = 40 VGPRs)
-constexpr long NEWTON_SPIN_LIMIT = 4000000L;  // polls (~1 us each) before a slice gives up
+static_assert(NEWTON_SLICE == NEWTON_SLICE_PAT, "kernels.h newton_split / newton_slice describe this kernel's slices");
 
 struct NewtonShared {
     double exl[NCAT * NS][2];                 // (exp(lambda_i r_k t), lambda_i r_k)
     double red[3][NEWTON_WAVES];              // streaming form: every wave's sums; register form: [.][0] = service wave A's
     double fb[3][NEWTON_SLICE];               // register form: per pattern f, f', f'' (the service waves finish them)
     double xs[2][NEWTON_ROWS][64];            // register form: the two service waves' sumtable rows (LDS instead of VGPRs)
+    double part[3][NEWTON_MAX_SPLIT];         // SEQ form: the slices' partial sums (what the split form exchanges)
     double bc[4];
+    int ticket;
 };
 
 // Wave specialisation (ROLE).  Every wave owns 16 patterns (lanes 4j..4j+3 own pattern j, each 20 of its 80 sumtable
@@ -660,19 +675,23 @@ struct NewtonShared {
 // of 64 patterns each, wave 7 the cross-workgroup exchange.  The roles are separate instantiations of one body, so the
 // register-hungry exp / log never meet 40 live sumtable registers: the kernel fits 8 waves per SIMD = 4 workgroups per CU
 // = every slice of 128 C3 genes resident at once.  All waves run the same Newton control flow on the same broadcast sums
-// and meet at the same four barriers per evaluation.  Slices > 128 patterns (genes of more than 8192 patterns) stream
+// and meet at the same barriers per evaluation.  Slices > 128 patterns (genes of more than 8192 patterns) stream
 // their rows from L2 in every evaluation (REG = false, a second kernel with a 128-VGPR budget).
-template <bool REG, int ROLE>
-__device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, const NewtonReq &r, NewtonShared &sh,
-                                            int S, int wg, int p_begin, int p_end) {
+// SEQ: the no-exchange fallback -- this ONE workgroup is every slice of the request in turn (rows re-read per evaluation).
+template <bool REG, int ROLE, bool SEQ>
+__device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, const NewtonReq &r, NewtonShared &sh, NewtonCtl *ctl,
+                                            int S, int wg, int slice, long long timeout_ticks) {
     constexpr bool SVC = ROLE != 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mpad = r.mpad;
     u64 *gran = reinterpret_cast<u64 *>(r.sync);       // [parity 2][slice NEWTON_MAX_SPLIT][6] granules, zeroed by the sumtable op
     int nevals = 0;
     bool failed = false;
     double xr[NEWTON_ROWS]; const int sub = tid & 3;
     double sw = 0.0, ss = 0.0;             // service waves: weight and scaling count of the pattern the lane finishes
-    if (REG) {
+    // the rows / weights of slice s (register form): once for the split form, per evaluation for SEQ
+    auto load_slice = [&](int s) {
+        const int p_begin = s * slice, p_end = min(mpad, p_begin + slice);
         // lanes beyond the slice read its last pattern (a valid address) and carry weight 0: no per-load branches
         const int p = p_begin + (tid >> 2), pc = min(p, p_end - 1);
         const double *col = r.sumtab + clv_index(sub * NEWTON_ROWS, pc);          // tiled sumtable: rows of a tile are 128 doubles apart
@@ -680,12 +699,14 @@ __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, con
 #pragma unroll 4
             for (int i = 0; i < NEWTON_ROWS; ++i) sh.xs[ROLE - 1][i][lane] = col[(size_t)i * TILE_PAT];      // read back by the same lane only
             const int pf = p_begin + 64 * (ROLE - 1) + lane;
+            sw = 0.0; ss = 0.0;
             if (pf < p_end) { sw = r.weight[pf]; ss = (double)r.scl[pf]; }
         } else {
 #pragma unroll
             for (int i = 0; i < NEWTON_ROWS; ++i) xr[i] = col[(size_t)i * TILE_PAT];
         }
-    }
+    };
+    if (REG && !SEQ) load_slice(wg);
     auto fill_exl = [&](double t) {        // service wave A: rows 0..39, B: rows 40..79
         if (lane < NCAT * NS / 2) {
             const int k = (ROLE - 1) * (NCAT * NS / 2) + lane;
@@ -693,11 +714,11 @@ __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, con
             sh.exl[k][0] = exp(lr * t); sh.exl[k][1] = lr;
         }
     };
-
-    auto eval_at = [&](double t, double &L, double &d1, double &d2) {
-        if (SVC) fill_exl(t);
-        __syncthreads();
+    // the three sums of slice s at the current sh.exl (ends with them in tot[] of service wave B, all waves past the same barriers)
+    auto slice_sums = [&](int s, double (&tot)[3]) {
+        const int p_begin = s * slice, p_end = min(mpad, p_begin + slice);
         if (REG) {
+            if (SEQ) load_slice(s);
             double f = 0.0, f1 = 0.0, f2 = 0.0;
 #pragma unroll
             for (int i = 0; i < NEWTON_ROWS; ++i) {
@@ -728,10 +749,10 @@ __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, con
                 acc[2] += w * (f2 / f - r1 * r1);
             }
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { const double s = wave_sum(acc[i]); if (lane == 0) sh.red[i][wave] = s; }
+            for (int i = 0; i < 3; ++i) { const double sm = wave_sum(acc[i]); if (lane == 0) sh.red[i][wave] = sm; }
         }
         __syncthreads();
-        double tot[3] = {0.0, 0.0, 0.0};
+        tot[0] = tot[1] = tot[2] = 0.0;
         if (SVC && REG) {                    // lane l of service wave A / B finishes pattern l / 64 + l of the slice
             double a0 = 0.0, a1 = 0.0, a2 = 0.0;
             if (sw != 0.0) {
@@ -743,44 +764,73 @@ __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, con
             if (ROLE == 1 && lane == 0) { sh.red[0][0] = tot[0]; sh.red[1][0] = tot[1]; sh.red[2][0] = tot[2]; }
         }
         __syncthreads();
-        if (ROLE == 2) {                     // service wave B: the workgroup's sums in a fixed order, then the exchange
+        if (ROLE == 2) {                     // service wave B: the slice's sums in a fixed order
             if (REG) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) tot[i] = sh.red[i][0] + __shfl(tot[i], 0);
             } else {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    double s = sh.red[i][0];
+                    double sm = sh.red[i][0];
 #pragma unroll
-                    for (int w = 1; w < NEWTON_WAVES; ++w) s += sh.red[i][w];
-                    tot[i] = s;
+                    for (int w = 1; w < NEWTON_WAVES; ++w) sm += sh.red[i][w];
+                    tot[i] = sm;
                 }
             }
+        }
+    };
+
+    auto eval_at = [&](double t, double &L, double &d1, double &d2) {
+        if (SVC) fill_exl(t);
+        __syncthreads();
+        double tot[3] = {0.0, 0.0, 0.0};
+        if (SEQ) {
+            for (int s = 0; s < S; ++s) {
+                slice_sums(s, tot);
+                if (ROLE == 2 && lane == 0) { sh.part[0][s] = tot[0]; sh.part[1][s] = tot[1]; sh.part[2][s] = tot[2]; }
+                __syncthreads();             // sh.fb / sh.red / sh.xs are reused by the next slice
+            }
+        } else slice_sums(wg, tot);
+        if (ROLE == 2) {
             bool bad = false;
             if (S > 1) {
-                const u64 want = (u64)(nevals + 1);
-                u64 *slot = gran + (size_t)((nevals & 1) * NEWTON_MAX_SPLIT) * 6;
-                if (lane < 6) {              // publish: six granules {tag, half of a double}, one lane each
-                    const int c = lane >> 1;
-                    const u64 bits = (u64)__double_as_longlong(c == 0 ? tot[0] : (c == 1 ? tot[1] : tot[2]));
-                    st_granule(slot + wg * 6 + lane, (want << 32) | ((lane & 1) ? (bits >> 32) : (bits & 0xFFFFFFFFull)));
-                }
-                u64 x[6] = {0, 0, 0, 0, 0, 0};
-                long spins = 0;
-                for (;;) {                   // gather: lane l re-reads slice l's granules until all six carry this evaluation's tag
-                    bool ok = true;
-                    if (lane < S) {
+                if (SEQ) {
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) { x[k] = ld_granule(slot + lane * 6 + k); ok = ok && (x[k] >> 32) == want; }
+                    for (int i = 0; i < 3; ++i) tot[i] = wave_sum(lane < S ? sh.part[i][lane] : 0.0);      // the split form's tree
+                } else {
+                    const u64 want = (u64)(nevals + 1);
+                    u64 *slot = gran + (size_t)((nevals & 1) * NEWTON_MAX_SPLIT) * 6;
+                    if (lane < 6) {              // publish: six granules {tag, half of a double}, one lane each
+                        const int c = lane >> 1;
+                        const u64 bits = (u64)__double_as_longlong(c == 0 ? tot[0] : (c == 1 ? tot[1] : tot[2]));
+                        st_granule(slot + wg * 6 + lane, (want << 32) | ((lane & 1) ? (bits >> 32) : (bits & 0xFFFFFFFFull)));
                     }
-                    if (__all(ok)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > NEWTON_SPIN_LIMIT) { bad = true; break; }      // bounded: never hang the GPU
-                }
+                    u64 x[6] = {0, 0, 0, 0, 0, 0};
+                    const long long t_start = wall_clock64();
+                    unsigned polls = 0;
+                    for (;;) {                   // gather: lane l re-reads slice l's granules until all six carry this evaluation's tag
+                        bool ok = true;
+                        if (lane < S) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {   // lanes >= S contribute +0.0 (exact); fixed shuffle tree: a function of S alone
-                    const u64 bits = ((x[2 * i + 1] & 0xFFFFFFFFull) << 32) | (x[2 * i] & 0xFFFFFFFFull);
-                    tot[i] = wave_sum(lane < S ? __longlong_as_double((long long)bits) : 0.0);
+                            for (int k = 0; k < 6; ++k) { x[k] = ld_granule(slot + lane * 6 + k); ok = ok && (x[k] >> 32) == want; }
+                        }
+                        if (__all(ok)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        // bounded in wall-clock time; a slice that gives up takes the whole launch (and the stream's later
+                        // launches) with it through the abort word, so the device drains instead of spinning bound after bound
+                        if ((++polls & 63u) == 0u || timeout_ticks == 0) {
+                            if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { bad = true; break; }
+                            if (wall_clock64() - t_start > timeout_ticks) {
+                                __hip_atomic_store(&ctl->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                bad = true; break;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {   // lanes >= S contribute +0.0 (exact); fixed shuffle tree: a function of S alone
+                        const u64 bits = ((x[2 * i + 1] & 0xFFFFFFFFull) << 32) | (x[2 * i] & 0xFFFFFFFFull);
+                        tot[i] = wave_sum(lane < S ? __longlong_as_double((long long)bits) : 0.0);
+                    }
                 }
             }
             if (lane == 0) { sh.bc[0] = tot[0]; sh.bc[1] = tot[1]; sh.bc[2] = tot[2]; if (bad) sh.bc[3] = 1.0; }
@@ -816,7 +866,7 @@ __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, con
         if (tiny) { t = tn; break; }
     }
     if (ROLE == 2 && lane == 0 && wg == 0) {
-        if (failed) { t = r.t0; L = __builtin_nan(""); }      // exchange timeout: reported, the host fails the call
+        if (failed) { t = r.t0; L = __builtin_nan(""); }      // exchange gave up: reported, the host re-issues the request (SEQ form)
         r.out[0] = t; r.out[1] = L; r.out[2] = d1; r.out[3] = d2;
         if (r.t_dev0) { *r.t_dev0 = t; *r.t_dev1 = t; }
     }
@@ -824,52 +874,77 @@ __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, con
         __syncthreads();
         if (SVC) fill_exl(t);
         __syncthreads();
-        if (REG) {
-            double f = 0.0;
-#pragma unroll
-            for (int i = 0; i < NEWTON_ROWS; ++i) f += (SVC ? sh.xs[ROLE - 1][i][lane] : xr[i]) * sh.exl[sub * NEWTON_ROWS + i][0];
-            f = quad_sum(f);
-            if (sub == 0) sh.fb[0][tid >> 2] = f;
-            __syncthreads();
-            if (SVC) {                           // the logs, again by the service waves
-                const int j = 64 * (ROLE - 1) + lane, p = p_begin + j;
-                if (p < p_end) r.patlnl[p] = (sw != 0.0) ? log(sh.fb[0][j] * 0.25) - ss * LOG_2_256 : 0.0;
-            }
-        } else {
-            for (int p = p_begin + tid; p < p_end; p += NEWTON_THREADS) {
+        for (int s = SEQ ? 0 : wg; s < (SEQ ? S : wg + 1); ++s) {
+            const int p_begin = s * slice, p_end = min(mpad, p_begin + slice);
+            if (REG) {
+                if (SEQ) load_slice(s);
                 double f = 0.0;
-                if (r.weight[p] != 0.0) {
-                    for (int row = 0; row < CLV_ROWS; ++row) f += r.sumtab[clv_index(row, p)] * sh.exl[row][0];
-                    f = log(f * 0.25) - r.scl[p] * LOG_2_256;
+#pragma unroll
+                for (int i = 0; i < NEWTON_ROWS; ++i) f += (SVC ? sh.xs[ROLE - 1][i][lane] : xr[i]) * sh.exl[sub * NEWTON_ROWS + i][0];
+                f = quad_sum(f);
+                if (sub == 0) sh.fb[0][tid >> 2] = f;
+                __syncthreads();
+                if (SVC) {                           // the logs, again by the service waves
+                    const int j = 64 * (ROLE - 1) + lane, p = p_begin + j;
+                    if (p < p_end) r.patlnl[p] = (sw != 0.0) ? log(sh.fb[0][j] * 0.25) - ss * LOG_2_256 : 0.0;
                 }
-                r.patlnl[p] = f;
+                if (SEQ) __syncthreads();
+            } else {
+                for (int p = p_begin + tid; p < p_end; p += NEWTON_THREADS) {
+                    double f = 0.0;
+                    if (r.weight[p] != 0.0) {
+                        for (int row = 0; row < CLV_ROWS; ++row) f += r.sumtab[clv_index(row, p)] * sh.exl[row][0];
+                        f = log(f * 0.25) - r.scl[p] * LOG_2_256;
+                    }
+                    r.patlnl[p] = f;
+                }
             }
         }
     }
 }
 
 // (the streaming form is a second kernel so that its loads do not cost the register-resident form its 8 waves per
-// SIMD; each kernel skips the other's requests)
-template <bool REG>
-__global__ __launch_bounds__(NEWTON_THREADS, REG ? 8 : 4) void k_newton(const ModelDev *__restrict__ md,
-                                                                        const NewtonReq *__restrict__ reqs) {
+// SIMD; each kernel has its own ticket table)
+// SEQ = false: one workgroup per TICKET (ticket -> request through `ticket_req`, slice = ticket - first ticket of the request);
+// SEQ = true : one workgroup per entry of `ticket_req` = one whole request (the host lists the requests to re-issue)
+template <bool REG, bool SEQ>
+__global__ __launch_bounds__(NEWTON_THREADS, (REG && !SEQ) ? 8 : 4) void k_newton(const ModelDev *__restrict__ md,
+                                                                                  const NewtonReq *__restrict__ reqs,
+                                                                                  const int *__restrict__ ticket_req, NewtonCtl *ctl,
+                                                                                  long long timeout_ticks) {
     __shared__ NewtonShared sh;
-    const NewtonReq &r = reqs[blockIdx.y];            // by reference: a private copy would live in scratch (rates[] is indexed dynamically)
-    const int mpad = r.mpad, wg = blockIdx.x;
+    constexpr int K = REG ? 0 : 1;
+    if (threadIdx.x == 0) {
+        sh.bc[3] = 0.0;
+        sh.ticket = SEQ ? (int)blockIdx.x : __hip_atomic_fetch_add(&ctl->ticket[K], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // a launch of a stream whose earlier launch gave up does not start spinning again: it reports NaN at once
+        if (!SEQ && __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) sh.bc[3] = 2.0;
+    }
+    __syncthreads();
+    const int ticket = sh.ticket;
+    const NewtonReq &r = reqs[ticket_req[ticket]];    // by reference: a private copy would live in scratch (rates[] is indexed dynamically)
+    const int mpad = r.mpad, wg = SEQ ? 0 : ticket - r.ticket0;
     // the split depends on the request alone (not on what else is in the launch): results are reproducible
     // whatever the batch composition
-    const int S = min(NEWTON_MAX_SPLIT, (mpad + NEWTON_SLICE - 1) / NEWTON_SLICE);
-    if (wg >= S) return;
-    // register form: a slice IS a tile of the sumtable (80 KB contiguous); beyond 64 tiles the slices grow and stream
-    const int slice = (mpad <= NEWTON_SLICE * NEWTON_MAX_SPLIT) ? NEWTON_SLICE : ((mpad / 32 + S - 1) / S) * 32;
-    if ((slice <= NEWTON_SLICE) != REG) return;
-    const int p_begin = wg * slice, p_end = min(mpad, p_begin + slice);
-    if (threadIdx.x == 0) sh.bc[3] = 0.0;
-    __syncthreads();
-    const int wave = threadIdx.x >> 6;
-    if (wave == NEWTON_WAVES - 1) newton_body<REG, 2>(md, r, sh, S, wg, p_begin, p_end);
-    else if (wave == NEWTON_WAVES - 2) newton_body<REG, 1>(md, r, sh, S, wg, p_begin, p_end);
-    else newton_body<REG, 0>(md, r, sh, S, wg, p_begin, p_end);
+    const int S = newton_split(mpad), slice = newton_slice(mpad);
+    if (sh.bc[3] == 2.0) {
+        if (threadIdx.x == 0 && wg == 0) { r.out[0] = r.t0; r.out[1] = __builtin_nan(""); r.out[2] = 0.0; r.out[3] = 0.0; }
+    } else {
+        const int wave = threadIdx.x >> 6;
+        if (wave == NEWTON_WAVES - 1) newton_body<REG, 2, SEQ>(md, r, sh, ctl, S, wg, slice, timeout_ticks);
+        else if (wave == NEWTON_WAVES - 2) newton_body<REG, 1, SEQ>(md, r, sh, ctl, S, wg, slice, timeout_ticks);
+        else newton_body<REG, 0, SEQ>(md, r, sh, ctl, S, wg, slice, timeout_ticks);
+    }
+    if (!SEQ) {                                   // the workgroup that finishes last re-arms the ticket counter for the stream's next launch
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int d = __hip_atomic_fetch_add(&ctl->done[K], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == (int)gridDim.x - 1) {
+                __hip_atomic_store(&ctl->ticket[K], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ctl->done[K], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1025,19 +1100,22 @@ void launch_reduce(const ReduceReq *reqs, int n, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_reduce, dim3(n), dim3(256), 0, s, reqs);
 }
-void launch_newton(const ModelDev *model, const NewtonReq *reqs, int n, int max_mpad, hipStream_t s) {
-    if (n <= 0) return;
-    int S = (max_mpad + NEWTON_SLICE - 1) / NEWTON_SLICE;       // grid width; each request uses its own split (k_newton)
-    S = S < 1 ? 1 : (S > NEWTON_MAX_SPLIT ? NEWTON_MAX_SPLIT : S);
-    // Not every workgroup of the launch has to be resident at once: workgroups are dispatched in grid order (x
-    // fastest, round-robin over the XCDs), so the lowest unfinished request always has all of its <= 64 slices
-    // resident or next in line on every XCD and can finish; later requests spin (bounded) until their turn.
-    const int chunk = 32768;
-    for (int off = 0; off < n; off += chunk) {
-        const int m = (n - off < chunk) ? n - off : chunk;
-        hipLaunchKernelGGL(k_newton<true>, dim3(S, m), dim3(NEWTON_THREADS), 0, s, model, reqs + off);
-        if (max_mpad > NEWTON_SLICE * NEWTON_MAX_SPLIT) hipLaunchKernelGGL(k_newton<false>, dim3(S, m), dim3(NEWTON_THREADS), 0, s, model, reqs + off);
-    }
+static long long newton_timeout_ticks() {
+    // wall-clock bound of one exchange wait, in 100 MHz ticks; PML_NEWTON_TIMEOUT_US is the test hook (0 = give up at the
+    // first unsuccessful poll: forces the SEQ fallback for every request that is split)
+    static const long long v = [] { const char *e = std::getenv("PML_NEWTON_TIMEOUT_US"); return e ? std::atoll(e) * 100LL : 2000000LL * 100LL; }();
+    return v;
+}
+void launch_newton(const ModelDev *model, const NewtonReq *reqs, const int *tickets, int nreg, int nstream, NewtonCtl *ctl, hipStream_t s) {
+    // one workgroup per ticket; `tickets` lists the register-form tickets first, then the streaming-form ones (engine.cpp
+    // builds it in request order).  No chunking, no co-residency requirement: see FORWARD PROGRESS above.
+    const long long to = newton_timeout_ticks();
+    if (nreg > 0) hipLaunchKernelGGL((k_newton<true, false>), dim3((unsigned)nreg), dim3(NEWTON_THREADS), 0, s, model, reqs, tickets, ctl, to);
+    if (nstream > 0) hipLaunchKernelGGL((k_newton<false, false>), dim3((unsigned)nstream), dim3(NEWTON_THREADS), 0, s, model, reqs, tickets + nreg, ctl, to);
+}
+void launch_newton_seq(const ModelDev *model, const NewtonReq *reqs, const int *req_list, int nreg, int nstream, NewtonCtl *ctl, hipStream_t s) {
+    if (nreg > 0) hipLaunchKernelGGL((k_newton<true, true>), dim3((unsigned)nreg), dim3(NEWTON_THREADS), 0, s, model, reqs, req_list, ctl, 0LL);
+    if (nstream > 0) hipLaunchKernelGGL((k_newton<false, true>), dim3((unsigned)nstream), dim3(NEWTON_THREADS), 0, s, model, reqs, req_list + nreg, ctl, 0LL);
 }
 
 }  // namespace pml

@@ -283,6 +283,12 @@ class Context:
         self._check(self.L.pml_coalescing_stats(self.ptr, C.byref(b), C.byref(r)))
         return {"batches": b.value, "requests": r.value}
 
+    def newton_fallbacks(self):
+        """how often k_newton's bounded exchange wait gave up on this context and work was re-issued through the no-exchange form"""
+        a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        self._check(self.L.pml_newton_fallbacks(self.ptr, C.byref(a), C.byref(b), C.byref(c)))
+        return {"giveups": a.value, "reissued": b.value, "seq_launches": c.value}
+
     def kernel_stats(self, reset=False):
         out = {}
         for name, k in KERNELS.items():

@@ -77,6 +77,23 @@ def test_c5_shaped_search_nni_spr(gpu_ctx, monkeypatch):
     print("C5 shape: lnL - lnL(optimised generating tree) =", np.round(diff, 3), "collapsed RF =", rf)
 
 
+def test_c5_shape_16_genes_one_with_all_500_taxa(gpu_ctx):
+    """16 genes of BASELINE configs[4] shape in ONE batched call, NNI + lazy SPR radius 5 from the NJ start: gene 0 carries all
+    500 taxa (the full 500-leaf search: 498 inner nodes, 1494 directed CLV slots), the others miss their own 20 % of them;
+    same properties as above, and the throughput of the call (the driver-visible C5 number: BASELINE's 2000-gene job is
+    250 such genes per GPU on eight GPUs)."""
+    import time
+    genes = [_c5_gene(9300, absent=0.0)] + [_c5_gene(9300 + i) for i in range(1, 16)]
+    assert len(genes[0][0]) == 500 and all(len(g[0]) == 400 for g in genes[1:])
+    G = [(g[0], g[1]) for g in genes]
+    t0 = time.perf_counter()
+    out = gpu_ctx.search(G, None, nni=True, spr_radius=5, epsilon=1e-3)
+    dt = time.perf_counter() - t0
+    diff, rf = _check_batch(gpu_ctx, genes, out, min_better=13, max_mean_rf=6.0)
+    print("C5 shape, 16 genes (one with all 500 taxa), NNI + SPR 5: %.1f s = %.2f gene-trees/s; lnL - lnL(optimised generating tree) = %s; collapsed RF = %s"
+          % (dt, 16 / dt, np.round(diff, 2), rf))
+
+
 def test_reduced_shape_search_vs_oracle(gpu_ctx, oracle_lib):
     """60 taxa x 600 sites: the same search (given start tree = the engine's parsimony tree, NNI + SPR radius 5) in the
     CPU oracle and on the device -- same tree (RF 0 over resolved branches) and |dlnL| < 1e-3, the north star's bar"""

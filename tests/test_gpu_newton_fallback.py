@@ -1,0 +1,65 @@
+"""k_newton's forward-progress design (kernels.hip "FORWARD PROGRESS"; VERDICT r02 item 2, gpurun_out/r05e.err): slices are
+claimed by ticket (no reliance on dispatch order), waits are bounded in wall-clock time, and a wait that gives up re-issues
+the work through the no-exchange form with the bits of the split form -- the call succeeds."""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from pepr_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(env_extra):
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), **env_extra)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "newton_harness.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return json.loads(p.stdout)
+
+
+def test_giveup_falls_back_to_the_no_exchange_form_with_identical_bits():
+    normal = _run({})
+    forced = _run({"PML_NEWTON_TIMEOUT_US": "0"})        # every split exchange gives up at its first unsuccessful poll
+    assert max(normal["npat"]) > 8192 and min(normal["npat"]) <= 128        # streaming form and single-slice requests are covered
+    assert normal["fallbacks"] == {"giveups": 0, "reissued": 0, "seq_launches": 0}
+    fb = forced["fallbacks"]
+    assert fb["giveups"] > 0 and fb["reissued"] > 0 and fb["seq_launches"] > 0
+    for key in normal:
+        if key != "fallbacks":
+            assert forced[key] == normal[key], key
+
+
+def test_two_contexts_search_concurrently_in_one_process(gpu_ctx):
+    """two contexts (two streams) of ONE process searching at the same time: both succeed and each gene gets the bits of a
+    lone search -- the layout whose spinning slices could starve each other under the old in-grid-order assumption"""
+    sets = [[synth.simulate_alignment(20 + 3 * (i % 3), 500 + 100 * (i % 4), 7000 + 100 * k + i) for i in range(12)] for k in range(2)]
+    lone = [gpu_ctx.search([(g[0], g[1]) for g in S], None, nni=True, spr_radius=5, seed=9) for S in sets]
+    ctxs = [engine.Context(0), engine.Context(0)]
+    got, errs = [None, None], [None, None]
+    barrier = threading.Barrier(2)
+
+    def work(k):
+        try:
+            barrier.wait()
+            got[k] = [ctxs[k].search([(g[0], g[1]) for g in sets[k]], None, nni=True, spr_radius=5, seed=9) for _ in range(2)]
+        except Exception as e:      # noqa: BLE001 -- reported below
+            errs[k] = e
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert errs == [None, None], errs
+    fb = [c.newton_fallbacks() for c in ctxs]
+    for k in range(2):
+        for rep in got[k]:
+            assert [(r["lnl"], r["alpha"], r["newick"]) for r in rep] == [(r["lnl"], r["alpha"], r["newick"]) for r in lone[k]]
+    print("fallbacks while sharing the GPU:", fb)
+    for c in ctxs:
+        c.close()
