@@ -440,12 +440,15 @@ def main():
             spr = {"gene_trees_per_sec": total / tspr, "seconds": tspr,
                    "algorithm": "randomised stepwise-addition parsimony start + model optimisation + NNI + lazy SPR (radius 5), eps 1e-3",
                    "rf_to_generating_tree_mean_rank0": float(np.mean([engine.rf_distance(genes[i][2], sout[i]["newick"]) for i in range(len(genes))]))}
+        nfb = sctx.newton_fallbacks()
         sctx.close()
         sdt, cold = rank_max(sdt, cold)
         search = {"gene_trees_per_sec": total / sdt, "seconds": sdt, "setup_seconds_rank0": tc,
                   "cold_first_call_seconds": cold, "cold_gene_trees_per_sec": total / cold, "second_call_seconds_rank0": warm1, "genes": total,
                   "algorithm": "NJ start + WAG+G4 model optimisation + NNI hill climbing (eps 1e-3); timed from host char rows to Newick",
                   "rf_to_generating_tree_mean_rank0": float(np.mean(rf)), "finite": bool(np.all(np.isfinite(slnl))),
+                  # k_newton exchange waits that gave up and were re-issued through the no-exchange form (0 on a GPU the rank has to itself)
+                  "newton_fallbacks_rank0": nfb,
                   # no closed form for a search -> measured call counts x the per-pattern byte figures / time
                   "work_rank0": {"launches": {k: v["launches"] for k, v in sst.items() if v["launches"] and not k.startswith("host")},
                                  "algorithmic_GB": {k: v["algo_bytes"] / 1e9 for k, v in sst.items() if v["algo_bytes"]},

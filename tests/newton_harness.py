@@ -10,7 +10,7 @@ from pepr_amd import engine, synth
 def main():
     ctx = engine.Context(0)
     out = {}
-    shapes = [(6, 90), (10, 400), (14, 1500), (24, 700), (12, 12000)]       # 1, 4, 12, 6 slices; the last one streams (> 8192 patterns)
+    shapes = [(6, 90), (10, 400), (14, 1500), (24, 700), (20, 12000)]       # 1, 3, 9, 6 slices; the last one streams (> 8192 patterns)
     genes = [synth.simulate_alignment(nt, ns, 500 + i, missing_frac=0.1 * (i % 2)) for i, (nt, ns) in enumerate(shapes)]
     A = [(g[0], g[1]) for g in genes]; T = [g[2] for g in genes]
     b = engine.Batch(ctx, A, T, alpha=0.8)
