@@ -405,13 +405,11 @@ def main():
             device arena, model optimisation, NNI search; returns (seconds, setup seconds, lnl, batch)"""
             sync_all()
             t0 = time.perf_counter()
-            if nchunks > 1:                 # does not fit at once: the one-shot call walks it in HBM-sized sub-batches
-                out = sctx.search(G, None, nni=True, spr_radius=0, epsilon=1e-3)
-                b, tset, l = _Trees([o["newick"] for o in out]), 0.0, np.array([o["lnl"] for o in out])
-            else:
-                b = engine.Batch(sctx, G, None, alpha=1.0)
-                tset = time.perf_counter() - t0
-                l, _ = b.search(True, True, 0, 1e-3)
+            # the one-shot call PEPR's tree builder would issue (pml_search_batch): it deals the genes over a few groups, each a
+            # device batch on its own stream with its own host thread (api.cpp), and walks gene lists that do not fit in HBM at
+            # once in sub-batches
+            out = sctx.search(G, None, nni=True, spr_radius=0, epsilon=1e-3)
+            b, tset, l = _Trees([o["newick"] for o in out]), 0.0, np.array([o["lnl"] for o in out])
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()

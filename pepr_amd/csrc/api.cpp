@@ -3,7 +3,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
+#include <thread>
 
 #include "../../include/peprml.h"
 #include "api_types.hpp"
@@ -64,6 +66,7 @@ int pml_create(const pml_config *cfg, pml_ctx **out) {
 
 void pml_destroy(pml_ctx *ctx) {
     if (!ctx) return;
+    for (auto &w : ctx->workers) w->destroy();
     ctx->c.destroy();
     delete ctx;
 }
@@ -91,6 +94,7 @@ static int batch_create_impl(pml_ctx *ctx, int n, const pml_alignment *alns, con
     pml_batch *b = new (std::nothrow) pml_batch();
     if (!b) return PML_ENOMEM;
     b->owner = ctx;
+    pml_drop_worker_caches(ctx);
     static_assert(sizeof(pml_alignment) == sizeof(pml_alignment_view), "alignment view layout");
     const int ncat = model ? model->ncat : 4;
     const double alpha = model ? model->alpha : 1.0;
@@ -209,12 +213,14 @@ static size_t gene_bytes_bound(const pml_alignment &a, bool score_only) {
     return slots * CLV_ROWS * ((mp + 127) / 128 * 128) * 8 + slots * mp * 4 + nt * mp + 64 * mp + (1 << 16);
 }
 
-static int oneshot_chunk(pml_ctx *ctx, int op, int n, const pml_alignment *alns, const char *const *newicks,
-                         const pml_model *model, const pml_search_opts *opts, int flags, pml_result *out) {
-    pml_batch *b = nullptr;
+// one device batch on context `c` (the caller's own or one of its workers): start trees, the requested operation, results
+static int oneshot_on(Ctx &c, int op, int n, const pml_alignment *alns, const char *const *newicks,
+                      const pml_model *model, const pml_search_opts *opts, int flags, pml_result *const *out, int share) {
+    pml_fpguard fpg;
     // RAxML starts `-f d` from a randomised stepwise-addition parsimony tree (-p seed): opts->seed != 0 asks for
     // that start for every gene without a given start tree (seed 0 = the deterministic NJ start)
     std::vector<std::string> pstart; std::vector<const char *> pnw;
+    static_assert(sizeof(pml_alignment) == sizeof(pml_alignment_view), "alignment view layout");
     if (op == OP_SEARCH && opts && opts->seed != 0) {
         std::vector<int> idx;
         for (int i = 0; i < n; ++i) if (!newicks || !newicks[i]) idx.push_back(i);
@@ -222,40 +228,104 @@ static int oneshot_chunk(pml_ctx *ctx, int op, int n, const pml_alignment *alns,
             std::vector<pml_alignment_view> views;
             for (int i : idx) views.push_back(pml_alignment_view{alns[i].ntax, alns[i].nsites, alns[i].names, alns[i].rows});
             std::vector<Tree> trees; std::vector<EncodedAlignment> enc; std::vector<long long> len; std::vector<int> moves;
-            if (int prc = parsimony_batch(&ctx->c, (int)idx.size(), views.data(), opts->seed, 20, trees, enc, len, moves)) return prc;
+            if (int prc = parsimony_batch(&c, (int)idx.size(), views.data(), opts->seed, 20, trees, enc, len, moves)) return prc;
             pstart.resize(n); pnw.assign(n, nullptr);
             for (int i = 0; i < n; ++i) if (newicks && newicks[i]) pnw[i] = newicks[i];
             for (size_t k = 0; k < idx.size(); ++k) { pstart[idx[k]] = trees[k].newick(enc[k].names, 6); pnw[idx[k]] = pstart[idx[k]].c_str(); }
             newicks = pnw.data();
         }
     }
-    int rc = batch_create_impl(ctx, n, alns, newicks, model, op == OP_SCORE, &b);
-    if (rc) return rc;
-    std::vector<double> lnl(n);
+    Batch b;
+    struct Drop { Batch &b; ~Drop() { b.destroy(); } } drop{b};
+    b.share = share;
+    int rc;
     try {
-        if (op == OP_SCORE) rc = b->b.score(std::vector<char>(), lnl.data());
+        rc = b.create(&c, n, reinterpret_cast<const pml_alignment_view *>(alns), newicks, model ? model->pi_mode : PML_PI_RAXML_3DP,
+                      model ? model->ncat : 4, model ? model->alpha : 1.0, op == OP_SCORE);
+        if (rc) return rc;
+        std::vector<double> lnl(n);
+        if (op == OP_SCORE) rc = b.score(std::vector<char>(), lnl.data());
         else if (op == OP_OPTIMIZE)
-            rc = b->b.optimize(opts ? opts->optimize_alpha != 0 : true, (opts && opts->epsilon > 0) ? opts->epsilon : 1e-4, lnl.data());
+            rc = b.optimize(opts ? opts->optimize_alpha != 0 : true, (opts && opts->epsilon > 0) ? opts->epsilon : 1e-4, lnl.data());
         else {
-            rc = opts ? b->b.set_constraints(opts->nconstraints, opts->constraint_ntax, opts->constraint_names, opts->constraint_rows) : 0;
-            if (!rc) rc = b->b.search(opts ? opts->nni != 0 : true, opts ? opts->spr_radius : 0, opts ? opts->optimize_alpha != 0 : true,
-                                      (opts && opts->epsilon > 0) ? opts->epsilon : 1e-3, lnl.data());
+            rc = opts ? b.set_constraints(opts->nconstraints, opts->constraint_ntax, opts->constraint_names, opts->constraint_rows) : 0;
+            if (!rc) rc = b.search(opts ? opts->nni != 0 : true, opts ? opts->spr_radius : 0, opts ? opts->optimize_alpha != 0 : true,
+                                   (opts && opts->epsilon > 0) ? opts->epsilon : 1e-3, lnl.data());
         }
         for (int i = 0; i < n && !rc; ++i) {
-            const Gene &G = b->b.genes[i];
-            pml_result &r = out[i];
+            const Gene &G = b.genes[i];
+            pml_result &r = *out[i];
             r.lnl = lnl[i]; r.alpha = G.alpha; r.tree_length = G.tree.length();
             r.npatterns = G.aln.npat; r.nsites = G.aln.nsites;
             r.newick = dup_string(G.tree.newick(G.aln.names, op == OP_SCORE ? 10 : 20));
             if (op == OP_SCORE && (flags & PML_WANT_SITE_LNL)) {
                 r.site_lnl = (double *)std::malloc(sizeof(double) * (G.aln.nsites > 0 ? G.aln.nsites : 1));
-                if (!r.site_lnl) rc = ctx->c.fail(PML_ENOMEM, "host allocation failed");
-                else rc = b->b.site_lnl(i, r.site_lnl);
+                if (!r.site_lnl) rc = c.fail(PML_ENOMEM, "host allocation failed");
+                else rc = b.site_lnl(i, r.site_lnl);
             }
         }
-    } catch (const std::bad_alloc &) { rc = ctx->c.fail(PML_ENOMEM, "host allocation failed"); }
-    catch (const std::exception &e) { rc = ctx->c.fail(PML_EINVAL, e.what()); }
-    b->b.destroy(); delete b;
+    } catch (const std::bad_alloc &) { rc = c.fail(PML_ENOMEM, "host allocation failed"); }
+    catch (const std::exception &e) { rc = c.fail(PML_EINVAL, e.what()); }
+    return rc;
+}
+
+// Worker contexts: a search is a chain of thousands of small dependent launches with host decisions in between (pass set-up,
+// NNI / SPR candidate selection, Brent steps), so ONE batch leaves the device idle whenever its host thread thinks and
+// latency-bound whenever a kernel of the chain is (four bench ranks forced onto one GPU searched 512 C3 genes at 181 / 118
+// gene-trees/s against 171 / 75 for one rank alone, profiles/r03_rehearsal_4_ranks_on_1_gpu.json).  Genes are independent and
+// a gene's arithmetic does not depend on what shares its batch, so a search call deals its genes over a few GROUPS, each a
+// batch of its own on its own stream driven by its own host thread: one group's host work and latency-bound kernels overlap
+// the others' device work.  Same bits as the undivided call (tests/test_gpu_parity.py: composition independence).
+static Ctx *worker_ctx(pml_ctx *ctx, int k) {
+    while ((int)ctx->workers.size() <= k) {
+        std::unique_ptr<Ctx> w(new Ctx());
+        if (w->init(ctx->c.device, false)) { ctx->c.last_error = w->last_error; return nullptr; }
+        ctx->workers.push_back(std::move(w));
+    }
+    return ctx->workers[k].get();
+}
+static int search_groups(int n, const pml_alignment *alns) {
+    // OFF by default (PML_GROUPS=1): measured on one box (gpurun_out/r3d_groups.txt), 4 groups of 32 C3 genes searched at 138
+    // gene-trees/s against 162 undivided -- hipFree / hipMalloc synchronise the whole DEVICE of a process, so the groups'
+    // buffer growth and the parsimony starts serialise them, which separate processes do not suffer
+    static const int env = std::getenv("PML_GROUPS") ? std::atoi(std::getenv("PML_GROUPS")) : 1;
+    (void)alns;
+    int g = std::max(1, std::min(env, 8));
+    while (g > 1 && n / g < 8) --g;               // a group below ~8 genes no longer fills the device's latency gaps
+    return g;
+}
+
+static int oneshot_chunk(pml_ctx *ctx, int op, int n, const pml_alignment *alns, const char *const *newicks,
+                         const pml_model *model, const pml_search_opts *opts, int flags, pml_result *out) {
+    const int G = (op == OP_SEARCH) ? search_groups(n, alns) : 1;
+    if (G <= 1) {
+        std::vector<pml_result *> outs(n);
+        for (int i = 0; i < n; ++i) outs[i] = out + i;
+        return oneshot_on(ctx->c, op, n, alns, newicks, model, opts, flags, outs.data(), 1);
+    }
+    // genes are dealt round-robin (the callers pass genes of similar size next to each other), group k on worker context k
+    for (int k = 0; k < G; ++k) if (!worker_ctx(ctx, k)) return PML_EDEVICE;
+    if (ctx->c.arena_cache) { hipFree(ctx->c.arena_cache); ctx->c.arena_cache = nullptr; ctx->c.arena_cache_bytes = 0; }   // the groups bring their own arenas
+    std::vector<int> rcs(G, 0);
+    std::vector<std::thread> th;
+    for (int k = 0; k < G; ++k) th.emplace_back([&, k]() {
+        std::vector<pml_alignment> a; std::vector<const char *> nw; std::vector<pml_result *> outs;
+        for (int i = k; i < n; i += G) { a.push_back(alns[i]); nw.push_back(newicks ? newicks[i] : nullptr); outs.push_back(out + i); }
+        try { rcs[k] = oneshot_on(*ctx->workers[k], op, (int)a.size(), a.data(), newicks ? nw.data() : nullptr, model, opts, flags, outs.data(), G); }
+        catch (const std::exception &e) { rcs[k] = ctx->workers[k]->fail(PML_EINVAL, e.what()); }
+    });
+    for (auto &t : th) t.join();
+    int rc = 0;
+    for (int k = 0; k < G; ++k) {
+        Ctx &w = *ctx->workers[k];
+        if (rcs[k] && !rc) { rc = rcs[k]; ctx->c.last_error = w.last_error; }
+        for (int i = 0; i < K_COUNT; ++i) {            // the workers' launch statistics count as the context's
+            ctx->c.stats[i].launches += w.stats[i].launches; ctx->c.stats[i].ms += w.stats[i].ms; ctx->c.stats[i].bytes += w.stats[i].bytes; ctx->c.stats[i].flops += w.stats[i].flops;
+            w.stats[i] = Ctx::KStat();
+        }
+        ctx->c.newton_giveups += w.newton_giveups; ctx->c.newton_reissued += w.newton_reissued; ctx->c.newton_seq_launches += w.newton_seq_launches;
+        w.newton_giveups = w.newton_reissued = w.newton_seq_launches = 0;
+    }
     return rc;
 }
 
@@ -275,6 +345,9 @@ static int oneshot(pml_ctx *ctx, int op, int n, const pml_alignment *alns, const
     hipSetDevice(ctx->c.device);
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)1 << 40;
     free_b += ctx->c.arena_cache_bytes;            // the cached arena is reused or released by the next batch
+    // the workers' cached arenas: reused by a grouped call, released before any other
+    if (op == OP_SEARCH) { for (auto &w : ctx->workers) free_b += w->arena_cache_bytes; }
+    else { for (auto &w : ctx->workers) free_b += w->arena_cache_bytes; pml_drop_worker_caches(ctx); }
     size_t budget = (size_t)(0.85 * (double)free_b);
     if (const char *e = std::getenv("PML_HBM_BUDGET_MB")) budget = (size_t)std::atoll(e) << 20;   // test hook
     int rc = 0, begin = 0;
@@ -484,6 +557,7 @@ int pml_gamma20_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const char
     pml_fpguard fpg;
     for (int i = 0; i < n; ++i) { std::memset(&out[i], 0, sizeof(pml_result)); if (!newicks[i]) return ctx->c.fail(PML_EINVAL, "newick required"); }
     std::lock_guard<std::mutex> lk(ctx->c.mu);
+    pml_drop_worker_caches(ctx);
     pml_model m = model ? *model : pml_model{4, 1.0, PML_PI_WAG_FULL};
     m.ncat = 4;
     // gene lists that do not fit in free HBM at once go through in consecutive sub-batches, like every other one-shot call
@@ -535,6 +609,7 @@ int pml_parsimony_batch(pml_ctx *ctx, int n, const pml_alignment *alns, const pm
     if (!ctx || !alns || !out || n <= 0) return PML_EINVAL;
     pml_fpguard fpg;
     std::lock_guard<std::mutex> lk(ctx->c.mu);
+    pml_drop_worker_caches(ctx);
     for (int i = 0; i < n; ++i) std::memset(&out[i], 0, sizeof(pml_result));
     try {
         if (hipSetDevice(ctx->c.device) != hipSuccess) return ctx->c.fail(PML_EDEVICE, "hipSetDevice failed");

@@ -599,7 +599,7 @@ int Batch::flush_deferred() {
         }
         if (L.nruns) {
             ctx->tic(K_NEWVIEW, L.algo_bytes, L.algo_flops);
-            launch_oplist((const NvOp *)(ds + L.o_ops), (const GeneRun *)(ds + L.o_runs), (int)L.nruns, L.max_mpad, L.any_pitch, L.any_chain, st);
+            launch_oplist((const NvOp *)(ds + L.o_ops), (const GeneRun *)(ds + L.o_runs), (int)L.nruns, L.max_mpad, L.any_pitch, L.any_chain, st, L.fused ? d_nctl + L.lane : nullptr);
             ctx->toc(); PML_SER();
         }
         if (L.stagger) hipEventRecord(ev_stagger, st);
@@ -608,7 +608,7 @@ int Batch::flush_deferred() {
             launch_reduce((const ReduceReq *)(ds + L.o_red), (int)L.neval, st);
             ctx->toc(); PML_SER();
         }
-        if (L.nnewton) {
+        if (L.nt_reg + L.nt_stream > 0) {
             ctx->tic(K_NEWTON, L.newton_bytes);
             if (L.seq) { launch_newton_seq(md, (const NewtonReq *)(ds + L.o_newt), (const int *)(ds + L.o_tick), L.nt_reg, L.nt_stream, d_nctl + L.lane, st); ++ctx->newton_seq_launches; }
             else launch_newton(md, (const NewtonReq *)(ds + L.o_newt), (const int *)(ds + L.o_tick), L.nt_reg, L.nt_stream, d_nctl + L.lane, st);
@@ -653,11 +653,18 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         nsync_buf = nullptr; nsync_c = 0;
         const size_t cap = std::max(nnewton * 2, (size_t)256);
         HIPCHK(hipMalloc((void **)&nsync_buf, cap * NEWTON_SYNC_DOUBLES * sizeof(double)));
+        // granule tags are (launch number << 10) + evaluation: a fresh block must not hold a matching tag by accident
+        HIPCHK(hipMemsetAsync(nsync_buf, 0, cap * NEWTON_SYNC_DOUBLES * sizeof(double), ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
         nsync_c = cap;
     }
     if (nnewton && !d_nctl) {
         HIPCHK(hipMalloc((void **)&d_nctl, 2 * sizeof(NewtonCtl)));
-        HIPCHK(hipMemset(d_nctl, 0, 2 * sizeof(NewtonCtl)));
+        // ON THE BATCH'S STREAM and waited for: a null-stream hipMemset returns before it has run and is not ordered against the
+        // non-blocking streams the kernels use -- landing inside the first k_newton it would re-issue tickets and leave the
+        // counters un-armed for the next launch (seen as time-outs and a memory fault when several batches shared the device)
+        HIPCHK(hipMemsetAsync(d_nctl, 0, 2 * sizeof(NewtonCtl), ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     const hipStream_t st = lane ? ctx->stream2 : ctx->stream;
     double *const frags_buf = lane ? d_frags2 : d_frags;
@@ -683,6 +690,15 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     ReduceReq *hred = (ReduceReq *)(hs + o_red);
     NewtonReq *hnewt = (NewtonReq *)(hs + o_newt);
     int *htick = (int *)(hs + o_tick);
+    if (nnewton) ++newton_launch_seq;
+    const unsigned tag_base = (newton_launch_seq & 0x3FFFFFu) << 10;
+    // fused branch Newton (kernels.h OPF_FUSED_NEWTON): a gene's only Newton tail, sitting behind all of its operations, is
+    // iterated inside k_oplist<11> on the register-resident sumtable; PML_NO_FUSE=1 is the A-B arm, safe mode (after an exchange
+    // gave up) runs unfused through the no-exchange k_newton form
+    static const bool fuse_env = std::getenv("PML_NO_FUSE") == nullptr && !(std::getenv("PML_CHAIN") && std::atoi(std::getenv("PML_CHAIN")) == 0);   // PML_CHAIN=0: the plain kernel only
+    const bool fuse_ok = fuse_env && !newton_safe_mode();
+    std::vector<char> fused_req(nnewton, 0);
+    bool any_fused = false;
     std::vector<int> tail_req(ntail, -1);          // tail -> index of its NewtonReq (failure handling below)
     const double *eig = ctx->d_eigfrags[pi_mode];
 
@@ -849,8 +865,12 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
                 double *stab = t.sumtab_dev ? t.sumtab_dev : G.d_sumtab[t.slot];
                 int *sscl = t.sumtab_dev ? reinterpret_cast<int *>(t.sumtab_dev + clv_doubles(mp)) : G.d_sumscl[t.slot];
                 d.out = stab; d.out_scl = sscl;
-                d.aux = nsync_buf + (size_t)in * NEWTON_SYNC_DOUBLES;
                 NewtonReq &nr = hnewt[in];
+                nr.md = ctx->d_model[pi_mode]; nr.tag_base = tag_base; nr.pad0 = 0;
+                if (fuse_ok && tails_of[g].size() == 1 && t.after < 0 && !t.patlnl_dev && newton_reg_form(mp)) {
+                    d.flags |= OPF_FUSED_NEWTON; d.aux = (const NewtonReq *)(ds + o_newt) + in;
+                    fused_req[in] = 1; any_fused = true; any_chain = true;
+                }
                 tail_req[&t - tails.data()] = (int)in;
                 nr.ticket0 = 0; nr.pad = 0;
                 nr.sumtab = stab; nr.weight = G.d_weight; nr.scl = sscl;
@@ -941,7 +961,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         int cur = 0;
         for (int pass = 0; pass < 2; ++pass) {
             for (size_t i = 0; i < nnewton; ++i) {
-                if (newton_reg_form(hnewt[i].mpad) != (pass == 0)) continue;
+                if (fused_req[i] || newton_reg_form(hnewt[i].mpad) != (pass == 0)) continue;
                 const int S = seq_launch ? 1 : newton_split(hnewt[i].mpad);
                 hnewt[i].ticket0 = cur - (pass == 0 ? 0 : nt_reg);            // relative to its kernel's table
                 for (int k = 0; k < S; ++k) htick[cur++] = (int)i;
@@ -951,10 +971,10 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         if (nnewton && safe_left > 0 && !safe_now) --safe_left;
     }
     double newton_bytes = 0;
-    for (auto &t : tails) if (t.mode < MODE_EVALUATE) newton_bytes += (double)genes[t.gene].aln.npat * 640;
+    for (size_t i = 0; i < ntail; ++i) if (tails[i].mode == MODE_SUMTABLE && !fused_req[tail_req[i]]) newton_bytes += (double)genes[tails[i].gene].aln.npat * 640;
     Deferred L;
     L.base = base; L.bytes = bytes; L.o_req = o_req; L.o_ops = o_ops; L.o_runs = o_runs; L.o_red = o_red; L.o_newt = o_newt;
-    L.o_tick = o_tick; L.nt_reg = nt_reg; L.nt_stream = nt_stream; L.seq = seq_launch;
+    L.o_tick = o_tick; L.nt_reg = nt_reg; L.nt_stream = nt_stream; L.seq = seq_launch; L.fused = any_fused;
     L.nreq = ireq; L.nruns = nruns; L.neval = neval; L.nnewton = nnewton; L.max_mpad = max_mpad; L.newton_maxm = newton_maxm;
     L.any_pitch = any_pitch; L.any_chain = any_chain; L.algo_bytes = algo_bytes; L.algo_flops = algo_flops; L.newton_bytes = newton_bytes; L.lane = lane; L.stagger = record_stagger;
     record_stagger = false;
@@ -989,7 +1009,20 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             const double *h = result_of(t);
             if (h && !std::isfinite(h[1])) bad.push_back(tail_req[i]);
         }
-        if (!bad.empty() && !seq_launch) {
+        bool bad_fused = false;
+        for (int i : bad) bad_fused = bad_fused || fused_req[i];
+        if (bad_fused && !in_retry) {
+            // a fused request has no stored sumtable to iterate on: the whole launch set runs again, unfused, through the
+            // no-exchange form (newton_gave_up() puts the batch in safe mode); CLV results are recomputed to the same bits
+            newton_gave_up(); ctx->newton_reissued += (long long)bad.size();
+            if (int rc = clear_abort()) return rc;
+            for (auto &o : ops) { o.unstored = false; if (o.out_kind == SIDE_MSG) genes[o.gene].pend_level[o.out_id] = -1; }
+            in_retry = true;
+            const int rc = run(ops, tails);
+            in_retry = false;
+            return rc;
+        }
+        if (!bad.empty() && !seq_launch && !bad_fused) {
             newton_gave_up(); ctx->newton_reissued += (long long)bad.size();
             int nr = 0, ns = 0;
             for (int pass = 0; pass < 2; ++pass) for (int i : bad) if (newton_reg_form(hnewt[i].mpad) == (pass == 0)) { htick[nr + ns] = i; ++(pass == 0 ? nr : ns); }

@@ -100,6 +100,7 @@ struct PendingOp { int gene, out_kind, out_id, level; Side child[2]; double t[2]
 struct Batch {
     Ctx *ctx = nullptr;
     int pi_mode = 0, ncat = 4, det_id = 0;
+    int share = 1;                 // batches working on the device at the same time (groups of one search call): free HBM is divided by it
     double newton_tol = 1e-8;      // Newton stop |dt| < tol: 1e-8 fine, 1e-6 in coarse phases
     std::vector<Gene> genes;
     char *arena = nullptr; size_t arena_bytes = 0;
@@ -120,6 +121,8 @@ struct Batch {
     // affected work is re-issued through the no-exchange SEQ form, and the next `safe_left` Newton launch sets use it from the
     // start (doubling hold-off, so a GPU that stays shared costs one time-out per hold-off period, not one per launch)
     int safe_left = 0, safe_hold = 4; bool safe_now = false;
+    unsigned newton_launch_seq = 0;      // launches with Newton tails so far: the exchange granules' tag base (never cleared, tags are unique)
+    bool in_retry = false;
     bool newton_safe_mode() { return safe_now || safe_left > 0; }
     void newton_gave_up();
     int clear_abort();
@@ -154,7 +157,7 @@ struct Batch {
     double *d_lenpool = nullptr;
     double *d_chain = nullptr, *h_chain = nullptr; size_t chain_cap = 0;     // 4 doubles per chained Newton result
     // a step of a chained pass whose upload + launches are issued later, grouped with its neighbours (flush_deferred)
-    struct Deferred { size_t base, bytes, o_req, o_ops, o_runs, o_red, o_newt, o_tick, nreq, nruns, neval, nnewton; int nt_reg, nt_stream; bool seq;
+    struct Deferred { size_t base, bytes, o_req, o_ops, o_runs, o_red, o_newt, o_tick, nreq, nruns, neval, nnewton; int nt_reg, nt_stream; bool seq, fused;
                       int max_mpad, newton_maxm, lane; bool any_pitch, any_chain, stagger; double algo_bytes, newton_bytes, algo_flops; };
     std::vector<Deferred> deferred; size_t flush_quota = 1; bool lanes_active = false;
     int flush_deferred();

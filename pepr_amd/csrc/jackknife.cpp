@@ -93,6 +93,7 @@ extern "C" int pml_debug_gather(pml_ctx *ctx, int ngenes, const pml_alignment *g
     if (!ctx || !genes || ngenes <= 0 || !ntax_out || !npat_out || !mpad_out || !codes_out || !weights_out || !names_out) return PML_EINVAL;
     *codes_out = nullptr; *weights_out = nullptr; *names_out = nullptr;
     std::lock_guard<std::mutex> lk(ctx->c.mu);
+    pml_drop_worker_caches(ctx);
     try {
         for (int g = 0; g < ngenes; ++g) if (!genes[g].names || !genes[g].rows || genes[g].ntax <= 0) return ctx->c.fail(PML_EINVAL, "bad alignment");
         std::vector<int> s;
@@ -132,6 +133,7 @@ extern "C" int pml_jackknife(pml_ctx *ctx, int ngenes, const pml_alignment *gene
     const int sworld = (opts && opts->shard_world > 1) ? opts->shard_world : 1, srank = sworld > 1 ? opts->shard_rank : 0;
     if (srank < 0 || srank >= sworld) return PML_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->c.mu);
+    pml_drop_worker_caches(ctx);
     try {
         std::vector<int> all(ngenes); for (int i = 0; i < ngenes; ++i) all[i] = i;
         for (int g = 0; g < ngenes; ++g) if (!genes[g].names || !genes[g].rows || genes[g].ntax <= 0) return ctx->c.fail(PML_EINVAL, "bad alignment");
@@ -223,6 +225,7 @@ extern "C" int pml_bootstrap(pml_ctx *ctx, const pml_alignment *aln, const pml_m
     if (replicate_newicks_out) *replicate_newicks_out = nullptr;
     const double eps = epsilon > 0 ? epsilon : 1e-3;
     std::lock_guard<std::mutex> lk(ctx->c.mu);
+    pml_drop_worker_caches(ctx);
     try {
         const int ncat = model ? model->ncat : 4, pm = model ? model->pi_mode : 0;
         const double alpha = model ? model->alpha : 1.0;

@@ -63,6 +63,11 @@ constexpr int OPF_NT_STORE = 16;
 // its last-computed child).  OPF_CHAIN_L / OPF_CHAIN_R: that side (kind SK_CLV) is taken from the registers instead of being
 // read back; OPF_NO_STORE: the result is consumed that way only and is not written at all (whole-tree scoring).
 constexpr int OPF_CHAIN_L = 32, OPF_CHAIN_R = 64, OPF_NO_STORE = 128;
+// Fused branch Newton (k_oplist<11>, round 3): a MODE_SUMTABLE operation that is the LAST operation of its gene in the launch
+// does not store its table -- a workgroup's tile of it (128 patterns x 80 rows) stays in the 80 VGPRs per wave that register
+// chaining reserves, and the gene's workgroups run makenewz on it in place (one exchange of three sums per evaluation, as in
+// k_newton).  Saves the sumtable's write and read (2 of the 5 CLV-sized transfers of a smoothing step), k_newton's launch and ramp.
+constexpr int OPF_FUSED_NEWTON = 256;
 struct OpSide {
     const void *p0, *p1, *p2;
     const double *t0, *t1, *t2;
@@ -82,7 +87,7 @@ struct NvOp {
     int flags;              // bits 0-1: left side kind, bits 2-3: right side kind, OPF_*
     int mode;               // MODE_NEWVIEW / MODE_SUMTABLE / MODE_EVALUATE
     int pad;
-    double *aux;            // sumtable ops: the Newton sync block to zero (NEWTON_SYNC_DOUBLES), else null
+    const void *aux;        // OPF_FUSED_NEWTON sumtable ops: the NewtonReq (device address) the workgroups of the gene iterate on, else null
 };
 static_assert(sizeof(NvOp) == 184, "NvOp layout");
 
@@ -107,7 +112,10 @@ struct NewtonReq {          // Newton-Raphson on one branch from its sumtable
     double t0;
     double tol;             // stop when |dt| < tol
     double *out;            // out[0]=t, out[1]=lnL, out[2]=d1, out[3]=d2 (at returned t)
-    double *sync;           // NEWTON_SYNC_DOUBLES zeroed 8-byte words: the slices' {tag, value} exchange granules (k_newton)
+    double *sync;           // NEWTON_SYNC_DOUBLES 8-byte words: the slices' {tag, value} exchange granules; never cleared: tags are unique
+    const ModelDev *md;     // eigenvalues of the gene's model
+    unsigned tag_base;      // (launch number << 10): granule tag = tag_base + evaluation number, so a block left by an earlier launch never matches
+    unsigned pad0;
     double *t_dev0, *t_dev1; // optional: device-resident copies of the branch length (both directions) for chaining
     double *patlnl;         // optional: per-pattern lnL (scaling applied) at the returned length, [mpad] (SH-like supports)
     int mpad;
@@ -124,7 +132,8 @@ __host__ __device__ constexpr int newton_slice(int mpad) { return mpad <= NEWTON
 __host__ __device__ constexpr bool newton_reg_form(int mpad) { return newton_slice(mpad) <= NEWTON_SLICE_PAT; }
 // per (batch, stream) control block of k_newton, zeroed once at allocation: ticket / done counters of the register-form [0]
 // and streaming-form [1] kernels (the last workgroup of a launch re-arms them) and the sticky abort word the host clears
-struct NewtonCtl { int ticket[2]; int done[2]; int abort; int pad[3]; };
+// oticket / odone: k_oplist launches with fused Newton tails claim (gene, tile) by ticket as well, one counter per XCD partition
+struct NewtonCtl { int ticket[2]; int done[2]; int abort; int odone; int pad[2]; int oticket[8]; };
 constexpr int NEWTON_SYNC_DOUBLES = 2 * NEWTON_MAX_SPLIT * 6;   // two parities x slices x six 8-byte {tag, half a double} granules (three partial sums)
 
 // MODE_EVALUATE_CAT: like MODE_EVALUATE but the four categories are NOT averaged: out[c][p] = sum_s L_c[s] (pi P_c . R_c)[s]
@@ -166,7 +175,8 @@ void launch_pmat(const ModelDev *model, const PmatReq *reqs, double *frags, int 
 //   set 0: x_i = sum_s pi_s U[s][i] A[s]     set 1: y_i = sum_j Uinv[i][j] B[j]
 void launch_eigfrags(const ModelDev *model, double *frags2, hipStream_t s);
 // any_pitch: some op has an SK_PITCH side (two more LDS fragment regions are allocated)
-void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, bool any_pitch, bool chained, hipStream_t s);
+// ctl != null: the launch has fused Newton tails (OPF_FUSED_NEWTON): chained variant, (gene, tile) claimed by ticket
+void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, bool any_pitch, bool chained, hipStream_t s, NewtonCtl *ctl = nullptr);
 void launch_reduce(const ReduceReq *reqs, int n, hipStream_t s);
 // tickets: request index per ticket, register-form tickets [0, nreg) then streaming-form [nreg, nreg + nstream)
 void launch_newton(const ModelDev *model, const NewtonReq *reqs, const int *tickets, int nreg, int nstream, NewtonCtl *ctl, hipStream_t s);

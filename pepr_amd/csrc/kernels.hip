@@ -166,6 +166,134 @@ __global__ __launch_bounds__(256) void k_eigfrags(const ModelDev *__restrict__ m
 }
 
 // ------------------------------------------------------------------------------------------
+// Branch Newton (makenewz): the pieces k_newton and the fused form inside k_oplist<11> share.  Both forms MUST produce the same
+// bits (the unfused + no-exchange form is the fallback of the fused one), so everything from a sumtable row to the Newton
+// step is written once, with floating-point contraction pinned where the two call sites could otherwise be compiled differently:
+//   per pattern   lane quarter q adds its 20 rows  c*20 + 4*st + q  (c = 0..3 outer, st = 0..4 inner; the rows an MFMA D tile
+//                 leaves in that lane) through newton_term, quarters are combined as (q0 + q1) + (q2 + q3);
+//   per slice     newton_finish per pattern, lane l of finishing wave A / B owns pattern l / 64 + l, wave_sum tree, A + B;
+//   per request   the slices' sums through newton_exchange (fixed shuffle tree over the slices), then newton_drive.
+// ------------------------------------------------------------------------------------------
+#define PML_TMIN 1.0e-6
+#define PML_TMAX 34.5
+
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+__device__ __forceinline__ void st_granule(u64 *p, u64 v) {
+    __hip_atomic_store((gu64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 ld_granule(const u64 *p) {
+    return __hip_atomic_load((const gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wave-uniform double kept in an SGPR pair (the Newton state is identical in every lane; as VGPRs it would cost 16 of 64)
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+// deterministic wave reduction: fixed shuffle tree
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+
+// one sumtable row x of a pattern at exp(lambda r t) = e, lambda r = lr:  f += x e,  f' += x e lr,  f'' += x e lr^2
+__device__ __forceinline__ void newton_term(double x, double e, double lr, double &f, double &f1, double &f2) {
+#pragma clang fp contract(off)
+    const double xe = x * e;
+    const double xl = xe * lr;
+    f = f + xe; f1 = f1 + xl; f2 = __builtin_fma(xl, lr, f2);
+}
+// a pattern's contribution to (lnL, dlnL/dt, d2lnL/dt2) from its f, f', f'' (weight w != 0, scaling count ss)
+__device__ __forceinline__ void newton_finish(double f, double f1, double f2, double w, double ss, double &a0, double &a1, double &a2) {
+#pragma clang fp contract(off)
+    const double r1 = f1 / f;
+    const double lg = log(f * 0.25);
+    a0 = w * (lg - ss * LOG_2_256); a1 = w * r1; a2 = w * (f2 / f - r1 * r1);
+}
+
+// Cross-workgroup exchange of one evaluation's three partial sums (executed by ONE whole wave of every slice's workgroup).
+// Data-tagged granules (cdna_hip_programming.md Guideline 16, form R2): every partial sum travels as two naturally aligned
+// 8-byte words {tag, 32 bits of the double}, each written by ONE relaxed agent-scope atomic store and read by relaxed
+// agent-scope atomic loads.  A granule is indivisible, so a consumer can never pair a tag with bytes of another evaluation;
+// no ordering between different words is needed (no flag, no fence, no s_waitcnt).  A slot is only overwritten two
+// evaluations later (parity double buffer), which its producer can reach only after every consumer has finished the
+// evaluation in between.  tag = tag_base (unique per launch) + evaluation number, so the block is never cleared.  The sums
+// of all slices are combined in a fixed tree order that depends on S alone, S depends on the request alone: bit-reproducible
+// whatever else is in the launch.  Returns true when the wait gave up (wall-clock bound or the launch-wide abort word).
+__device__ __forceinline__ bool newton_exchange(u64 *gran, int S, int wg, int nevals, unsigned tag_base, double (&tot)[3],
+                                                NewtonCtl *ctl, long long timeout_ticks) {
+    const int lane = threadIdx.x & 63;
+    const u64 want = (u64)(tag_base + (unsigned)nevals + 1u);
+    u64 *slot = gran + (size_t)((nevals & 1) * NEWTON_MAX_SPLIT) * 6;
+    if (lane < 6) {              // publish: six granules {tag, half of a double}, one lane each
+        const int c = lane >> 1;
+        const u64 bits = (u64)__double_as_longlong(c == 0 ? tot[0] : (c == 1 ? tot[1] : tot[2]));
+        st_granule(slot + wg * 6 + lane, (want << 32) | ((lane & 1) ? (bits >> 32) : (bits & 0xFFFFFFFFull)));
+    }
+    u64 x[6] = {0, 0, 0, 0, 0, 0};
+    const long long t_start = wall_clock64();
+    unsigned polls = 0;
+    bool bad = false;
+    for (;;) {                   // gather: lane l re-reads slice l's granules until all six carry this evaluation's tag
+        bool ok = true;
+        if (lane < S) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { x[k] = ld_granule(slot + lane * 6 + k); ok = ok && (x[k] >> 32) == want; }
+        }
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+        // bounded in wall-clock time; a slice that gives up takes the whole launch (and the stream's later launches) with it
+        // through the abort word, so the device drains instead of spinning bound after bound
+        if ((++polls & 63u) == 0u || timeout_ticks == 0) {
+            if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { bad = true; break; }
+            if (wall_clock64() - t_start > timeout_ticks) {
+                __hip_atomic_store(&ctl->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bad = true; break;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {   // lanes >= S contribute +0.0 (exact); fixed shuffle tree: a function of S alone
+        const u64 bits = ((x[2 * i + 1] & 0xFFFFFFFFull) << 32) | (x[2 * i] & 0xFFFFFFFFull);
+        tot[i] = wave_sum(lane < S ? __longlong_as_double((long long)bits) : 0.0);
+    }
+    return bad;
+}
+
+// Newton-Raphson with step control: the oracle's eng_newton_branch().  eval_at(t, L, d1, d2) -> false when the exchange gave up.
+// Wave-uniform; every wave of every slice runs it on the same broadcast sums.
+template <class Eval>
+__device__ __forceinline__ bool newton_drive(double t0, int max_iter, double tol, Eval &&eval_at, double &t, double &L, double &d1, double &d2) {
+    t = t0;
+    if (max_iter > 0) t = t < PML_TMIN ? PML_TMIN : (t > PML_TMAX ? PML_TMAX : t);
+    t = uni(t);
+    L = 0.0; d1 = 0.0; d2 = 0.0;
+    double tn = t;
+    bool first = true, failed = false;
+    int it = 0, bt = 0;
+    for (;;) {                                          // one evaluation site: initial point, Newton steps and backtracks
+        double Ln, n1, n2;
+        if (!eval_at(tn, Ln, n1, n2)) failed = true;
+        if (first) { first = false; L = Ln; d1 = n1; d2 = n2; }
+        else {
+            if (!(failed || Ln >= L - 1e-9 || bt >= 8)) { ++bt; tn = 0.5 * (tn + t); tn = uni(tn < PML_TMIN ? PML_TMIN : (tn > PML_TMAX ? PML_TMAX : tn)); continue; }
+            if (failed || Ln < L - 1e-9) break;
+            const double dt = fabs(tn - t);
+            t = tn; L = Ln; d1 = n1; d2 = n2; ++it;
+            if (dt < tol) break;
+        }
+        if (it >= max_iter || failed) break;
+        const double step = (d2 < 0.0) ? -d1 / d2 : (d1 > 0.0 ? t : -0.5 * t);
+        tn = t + step; bt = 0;
+        const bool tiny = fabs(step) < tol && d2 < 0.0;   // converged: take the (sub-tolerance) step unevaluated
+        tn = uni(tn < PML_TMIN ? PML_TMIN : (tn > PML_TMAX ? PML_TMAX : tn));
+        if (tiny) { t = tn; break; }
+    }
+    return !failed;
+}
+
+// ------------------------------------------------------------------------------------------
 // CLV op on one chunk (32 patterns) of one wave.
 //   MODE_NEWVIEW : out[c][s] = (P_L,c . L_c)[s] * (P_R,c . R_c)[s], 2^256 rescue, scaling counts
 //   MODE_SUMTABLE: same contraction with the eigen-basis matrices (no rescue), counts = l + r
@@ -297,7 +425,7 @@ __device__ __forceinline__ void load_pitch(Operand &o, const OpSide &sd, const d
 #ifndef PML_TIPLOOK
 #define PML_TIPLOOK 1
 #endif
-template <bool PREFETCH, bool CHAIN>
+template <bool PREFETCH, bool CHAIN, bool FUSE>
 __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restrict__ sP, const unsigned char *__restrict__ sT,
                                          int p, int lane, Operand (&X)[4], ivec2 &xsc) {
     // `op` refers to the descriptor in global memory (wave-uniform): fields are fetched by scalar loads
@@ -312,7 +440,9 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
     const int mode = op.mode;
     // register chaining (kernels.h OPF_CHAIN_*): X[0..3] = the four categories of the wave's last newview result, xsc its counts
     const bool chL = CHAIN && (op.flags & OPF_CHAIN_L) != 0, chR = CHAIN && (op.flags & OPF_CHAIN_R) != 0;
-    const bool keep = !(CHAIN && (op.flags & OPF_NO_STORE) != 0);
+    // fused branch Newton: the sumtable tile is not stored, it stays in X for newton_fused (its counts in xsc)
+    const bool fusedN = FUSE && (op.flags & OPF_FUSED_NEWTON) != 0;
+    const bool keep = !(CHAIN && (op.flags & OPF_NO_STORE) != 0) && !fusedN;
     constexpr bool TIPLOOK = PML_TIPLOOK != 0;
     constexpr bool PF_L = PREFETCH && !CHAIN;       // the chained variants prefetch the right side only (the chained child is the left one; registers)
     // (a plain tip side goes through the MFMA with its 0/1 indicator operand: the matrix pipe has slack and
@@ -401,7 +531,7 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
             } else contract_stream(fR + c * 25 * 16, curR, emit);
         }
         if (CHAIN) {
-            if (CAT_UNROLL == NCAT) { if (mode == MODE_NEWVIEW) X[c] = Y; }
+            if (CAT_UNROLL == NCAT) { if (mode == MODE_NEWVIEW || fusedN) X[c] = Y; }
             else if (mode == MODE_NEWVIEW) { X[0] = X[1]; X[1] = X[2]; X[2] = X[3]; X[3] = Y; }
             else if (chL || chR) { const Operand t = X[0]; X[0] = X[1]; X[1] = X[2]; X[2] = X[3]; X[3] = t; }   // a tail leaves X as it was
         }
@@ -445,7 +575,8 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
         if (q == 0) { sc.x += n0 ? 1 : 0; sc.y += n1 ? 1 : 0; if (keep) *reinterpret_cast<GLOBAL_AS ivec2 *>((gptr)op.out_scl + 4 * p) = sc; }
         if (CHAIN) xsc = sc;
     } else if (mode == MODE_SUMTABLE || mode == MODE_EVALUATE_CAT) {
-        if (q == 0) *reinterpret_cast<GLOBAL_AS ivec2 *>((gptr)op.out_scl + 4 * p) = sc;
+        if (fusedN) xsc = sc;
+        else if (q == 0) *reinterpret_cast<GLOBAL_AS ivec2 *>((gptr)op.out_scl + 4 * p) = sc;
     } else {
         site0 += __shfl_xor(site0, 16); site0 += __shfl_xor(site0, 32);
         site1 += __shfl_xor(site1, 16); site1 += __shfl_xor(site1, 32);
@@ -489,14 +620,101 @@ __device__ __forceinline__ void stage_frags_dma3(const NvOp &op, double *dst, in
     }
 }
 
+// Fused branch Newton (OPF_FUSED_NEWTON): the workgroups of one gene -- one 128-pattern tile of the sumtable each, in X --
+// iterate makenewz in place.  Same per-pattern order, finishing lanes, wave sums, exchange and step control as k_newton
+// (shared helpers above), hence its bits: waves 0 / 1 are k_newton's service waves A / B (80 exponentials per evaluation by
+// threads 0..79, logs and divisions of patterns l / 64 + l, wave 1 the exchange), all four waves add their patterns' rows.
+// `scratch` = the current parity's fragment region (the eigen-basis fragments the sumtable operation has finished with).
+struct FusedShared {
+    double exl[NCAT * NS][2];
+    double red[3];
+    double fb[3][PAT_PER_WAVE * 4];
+    double ss[PAT_PER_WAVE * 4];
+    double bc[4];
+};
+static_assert(sizeof(FusedShared) <= PFRAG * sizeof(double), "fused Newton scratch fits one fragment region");
+__device__ __forceinline__ void newton_fused(const NvOp &op, double *scratch, const Operand (&X)[4], const ivec2 xsc,
+                                             bool active, int blk, NewtonCtl *ctl, long long timeout_ticks) {
+    const NewtonReq &r = *reinterpret_cast<const NewtonReq *>(op.aux);
+    FusedShared &sh = *reinterpret_cast<FusedShared *>(scratch);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, pl = wave * PAT_PER_WAVE + 2 * (lane & 15);
+    const int mpad = r.mpad, S = newton_split(mpad);
+    const ModelDev *__restrict__ md = r.md;
+    u64 *gran = reinterpret_cast<u64 *>(r.sync);
+    __syncthreads();                       // every wave has finished the sumtable operation: its fragments may be overwritten
+    if (q == 0) { sh.ss[pl] = active ? (double)xsc.x : 0.0; sh.ss[pl + 1] = active ? (double)xsc.y : 0.0; }
+    if (tid == 0) sh.bc[3] = 0.0;
+    double sw = 0.0;                       // finishing lanes (waves 0, 1): weight of pattern wave * 64 + lane of the tile
+    if (wave < 2) { const int pf = blk * (PAT_PER_WAVE * 4) + wave * 64 + lane; if (pf < mpad) sw = r.weight[pf]; }
+    int nevals = 0;
+    auto eval_at = [&](double t, double &L, double &d1, double &d2) -> bool {
+        if (tid < NCAT * NS) {
+            const double lr = md->eval[tid % NS] * r.rates[tid / NS];
+            sh.exl[tid][0] = exp(lr * t); sh.exl[tid][1] = lr;
+        }
+        __syncthreads();
+        double fa = 0.0, fa1 = 0.0, fa2 = 0.0, fb = 0.0, fb1 = 0.0, fb2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCAT; ++c)
+#pragma unroll
+            for (int st = 0; st < 5; ++st) {
+                const int row = c * NS + 4 * st + q;
+                const double e = sh.exl[row][0], lr = sh.exl[row][1];
+                newton_term(X[c].v[st].x, e, lr, fa, fa1, fa2);
+                newton_term(X[c].v[st].y, e, lr, fb, fb1, fb2);
+            }
+        // quarters: (q0 + q1) + (q2 + q3), as quad_sum combines them in k_newton
+        fa += __shfl_xor(fa, 16); fa += __shfl_xor(fa, 32); fa1 += __shfl_xor(fa1, 16); fa1 += __shfl_xor(fa1, 32); fa2 += __shfl_xor(fa2, 16); fa2 += __shfl_xor(fa2, 32);
+        fb += __shfl_xor(fb, 16); fb += __shfl_xor(fb, 32); fb1 += __shfl_xor(fb1, 16); fb1 += __shfl_xor(fb1, 32); fb2 += __shfl_xor(fb2, 16); fb2 += __shfl_xor(fb2, 32);
+        if (q == 0) {
+            sh.fb[0][pl] = fa; sh.fb[1][pl] = fa1; sh.fb[2][pl] = fa2;
+            sh.fb[0][pl + 1] = fb; sh.fb[1][pl + 1] = fb1; sh.fb[2][pl + 1] = fb2;
+        }
+        __syncthreads();
+        double tot[3] = {0.0, 0.0, 0.0};
+        if (wave < 2) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            if (sw != 0.0) {
+                const int j = wave * 64 + lane;
+                newton_finish(sh.fb[0][j], sh.fb[1][j], sh.fb[2][j], sw, sh.ss[j], a0, a1, a2);
+            }
+            tot[0] = wave_sum(a0); tot[1] = wave_sum(a1); tot[2] = wave_sum(a2);
+            if (wave == 0 && lane == 0) { sh.red[0] = tot[0]; sh.red[1] = tot[1]; sh.red[2] = tot[2]; }
+        }
+        __syncthreads();
+        if (wave == 1) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tot[i] = sh.red[i] + __shfl(tot[i], 0);
+            bool bad = false;
+            if (S > 1) bad = newton_exchange(gran, S, blk, nevals, r.tag_base, tot, ctl, timeout_ticks);
+            if (lane == 0) { sh.bc[0] = tot[0]; sh.bc[1] = tot[1]; sh.bc[2] = tot[2]; if (bad) sh.bc[3] = 1.0; }
+        }
+        __syncthreads();
+        ++nevals;
+        L = uni(sh.bc[0]); d1 = uni(sh.bc[1]); d2 = uni(sh.bc[2]);
+        return sh.bc[3] == 0.0;
+    };
+    double t, L, d1, d2;
+    const bool ok = newton_drive(r.t0, r.max_iter, r.tol, eval_at, t, L, d1, d2);
+    if (tid == 64 && blk == 0) {           // wave 1, lane 0 of the gene's first tile
+        if (!ok) { t = r.t0; L = __builtin_nan(""); }      // exchange gave up: the host re-issues the step unfused (no-exchange form)
+        r.out[0] = t; r.out[1] = L; r.out[2] = d1; r.out[3] = d2;
+        if (r.t_dev0) { *r.t_dev0 = t; *r.t_dev1 = t; }
+    }
+}
+
 template <int VARIANT>
 // VARIANT 5 = variant 1 compiled for 3 waves/SIMD (168 VGPRs, no spills)
 // VARIANT 9 = variant 1 with register chaining (kernels.h OPF_CHAIN_*): 80 more live VGPRs, 2 waves/SIMD
 // VARIANT 11 = 9 + double-buffered fragment staging by LDS-DMA, three regions per parity (2 workgroups per CU leave 80 KB each)
+// VARIANT 15 = 11 + fused branch Newton (OPF_FUSED_NEWTON) and ticketed slots: the launches of the search that carry Newton
+//              tails; a variant of its own so that the Newton code (exp, log, exchange) costs the scoring kernel no register
 __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : (VARIANT >= 8) ? PML_CHAIN_WAVES : 3) void k_oplist(
-        const NvOp *__restrict__ ops, const GeneRun *__restrict__ runs, int nruns, int blocks_per_gene, int any_pitch) {
+        const NvOp *__restrict__ ops, const GeneRun *__restrict__ runs, int nruns, int blocks_per_gene, int any_pitch,
+        NewtonCtl *ctl, long long timeout_ticks) {
     constexpr bool PREFETCH = !(VARIANT & 1);
-    constexpr bool CHAIN = VARIANT >= 8;                  // 8..11: bit 0 / bit 1 as above, three LDS regions per parity
+    constexpr bool CHAIN = VARIANT >= 8;                  // 8..11, 15: bit 0 / bit 1 as above, three LDS regions per parity
+    constexpr bool FUSE = VARIANT == 15;
     constexpr bool DBUF3 = CHAIN && (VARIANT & 2) != 0;
     constexpr bool DBUF = ((VARIANT & 2) != 0 && VARIANT < 4) || DBUF3;
     constexpr int PARITY_STRIDE = (DBUF3 ? 3 : 2) * PFRAG;
@@ -513,14 +731,38 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : (VARIANT >= 8) ? PML_CHAI
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share
     // an XCD and its L2), so all pattern blocks of one gene get the same blockIdx % 8: the gene's
     // transition-matrix fragments are then fetched into ONE L2 instead of eight (speed only).
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int gi = xcd + 8 * (slot / blocks_per_gene), blk = slot % blocks_per_gene;
-    if (gi >= nruns) return;
-    const GeneRun run = runs[gi];
-    if (run.op_begin >= run.op_end) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xcd = blockIdx.x & 7;
+    int slot = blockIdx.x >> 3;
+    // Launches with fused Newton tails (ctl != null): the gene's workgroups exchange sums, i.e. WAIT for each other, so the
+    // slot is not tied to blockIdx but claimed by ticket when the workgroup starts (one counter per XCD partition, which keeps
+    // a gene's tiles on one XCD): whoever holds a ticket is running, and so are the holders of all lower tickets of the
+    // partition -- every gene but the newest is fully staffed (kernels.hip "FORWARD PROGRESS" at k_newton).
+    const bool ticketed = FUSE && ctl != nullptr;
+    if (ticketed) {
+        __shared__ int s_slot;
+        if (tid == 0) s_slot = __hip_atomic_fetch_add(&ctl->oticket[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        slot = s_slot;
+    }
+    auto leave = [&]() {                   // the workgroup that finishes last re-arms the ticket counters for the stream's next launch
+        if (!ticketed) return;
+        __syncthreads();
+        if (tid == 0) {
+            const int d = __hip_atomic_fetch_add(&ctl->odone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == (int)gridDim.x - 1) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) __hip_atomic_store(&ctl->oticket[k], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ctl->odone, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    const int gi = xcd + 8 * (slot / blocks_per_gene), blk = slot % blocks_per_gene;
+    if (gi >= nruns) { leave(); return; }
+    const GeneRun run = runs[gi];
+    if (run.op_begin >= run.op_end) { leave(); return; }
     const int mpad = ops[run.op_begin].mpad;            // constant per gene
-    if (blk * PAT_PER_WG >= mpad) return;
+    if (blk * PAT_PER_WG >= mpad) { leave(); return; }
     const int p = (blk * 4 + wave) * PAT_PER_WAVE + 2 * (lane & 15);
     const bool active = (blk * 4 + wave) * PAT_PER_WAVE < mpad;
 
@@ -556,20 +798,22 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : (VARIANT >= 8) ? PML_CHAI
             }
             __syncthreads();
         }
-        if (active) chunk_op<PREFETCH, CHAIN>(op, buf, sT, p, lane, X, xsc);
-        if (op.aux != nullptr && blk == 0) for (int i = tid; i < NEWTON_SYNC_DOUBLES; i += 256) op.aux[i] = 0.0;   // arm k_newton's arrival counter
+        if (active) chunk_op<PREFETCH, CHAIN, FUSE>(op, buf, sT, p, lane, X, xsc);
+        if (FUSE && (op.flags & OPF_FUSED_NEWTON) != 0) {
+            // a launch-wide abort (an exchange of this stream gave up earlier) is honoured before waiting on anybody
+            if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                const NewtonReq &r = *reinterpret_cast<const NewtonReq *>(op.aux);
+                if (tid == 0 && blk == 0) { r.out[0] = r.t0; r.out[1] = __builtin_nan(""); r.out[2] = 0.0; r.out[3] = 0.0; }
+            } else newton_fused(op, const_cast<double *>(buf), X, xsc, active, blk, ctl, timeout_ticks);
+        }
         if (DBUF) __syncthreads();           // next fragments landed (vmcnt(0) + barrier), stores done
     }
+    leave();
 }
 
 // ------------------------------------------------------------------------------------------
 // deterministic block reduction (fixed order: wave shuffle tree, then waves in index order)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-    return v;
-}
 template <int N, int WAVES>
 __device__ __forceinline__ void block_sum(double (&v)[N], double (*red)[WAVES]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -635,23 +879,6 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceReq *__restrict__ re
 // bits of the split form (engine.cpp: Batch::run / smooth_pass; tests/test_gpu_newton_fallback.py).
 // Control flow is the oracle's eng_newton_branch().
 // ------------------------------------------------------------------------------------------
-#define PML_TMIN 1.0e-6
-#define PML_TMAX 34.5
-
-typedef unsigned long long u64;
-typedef __attribute__((address_space(1))) u64 gu64;
-__device__ __forceinline__ void st_granule(u64 *p, u64 v) {
-    __hip_atomic_store((gu64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ u64 ld_granule(const u64 *p) {
-    return __hip_atomic_load((const gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// wave-uniform double kept in an SGPR pair (the Newton state is identical in every lane; as VGPRs it would cost 16 of 64)
-__device__ __forceinline__ double uni(double v) {
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-}
-
 constexpr int NEWTON_THREADS = 512;           // 8 waves, four lanes per pattern -> 128 patterns per workgroup
 constexpr int NEWTON_WAVES = NEWTON_THREADS / 64;
 constexpr int NEWTON_SLICE = NEWTON_WAVES * 16;           // patterns per register-resident slice
@@ -679,31 +906,34 @@ struct NewtonShared {
 // their rows from L2 in every evaluation (REG = false, a second kernel with a 128-VGPR budget).
 // SEQ: the no-exchange fallback -- this ONE workgroup is every slice of the request in turn (rows re-read per evaluation).
 template <bool REG, int ROLE, bool SEQ>
-__device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, const NewtonReq &r, NewtonShared &sh, NewtonCtl *ctl,
+__device__ __forceinline__ void newton_body(const NewtonReq &r, NewtonShared &sh, NewtonCtl *ctl,
                                             int S, int wg, int slice, long long timeout_ticks) {
     constexpr bool SVC = ROLE != 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mpad = r.mpad;
-    u64 *gran = reinterpret_cast<u64 *>(r.sync);       // [parity 2][slice NEWTON_MAX_SPLIT][6] granules, zeroed by the sumtable op
+    const ModelDev *__restrict__ md = r.md;
+    u64 *gran = reinterpret_cast<u64 *>(r.sync);       // [parity 2][slice NEWTON_MAX_SPLIT][6] granules
     int nevals = 0;
-    bool failed = false;
     double xr[NEWTON_ROWS]; const int sub = tid & 3;
     double sw = 0.0, ss = 0.0;             // service waves: weight and scaling count of the pattern the lane finishes
+    // lane quarter `sub` owns rows c*20 + 4*st + sub (i = c*5 + st): the rows an MFMA D tile leaves in that quarter, so the
+    // fused form (k_oplist<11>) adds the same rows in the same order
+    auto row_of = [&](int i) { return (i / 5) * NS + 4 * (i % 5) + sub; };
     // the rows / weights of slice s (register form): once for the split form, per evaluation for SEQ
     auto load_slice = [&](int s) {
         const int p_begin = s * slice, p_end = min(mpad, p_begin + slice);
         // lanes beyond the slice read its last pattern (a valid address) and carry weight 0: no per-load branches
         const int p = p_begin + (tid >> 2), pc = min(p, p_end - 1);
-        const double *col = r.sumtab + clv_index(sub * NEWTON_ROWS, pc);          // tiled sumtable: rows of a tile are 128 doubles apart
+        const double *col = r.sumtab + clv_index(sub, pc);          // tiled sumtable: rows of a tile are 128 doubles apart
         if (SVC) {
 #pragma unroll 4
-            for (int i = 0; i < NEWTON_ROWS; ++i) sh.xs[ROLE - 1][i][lane] = col[(size_t)i * TILE_PAT];      // read back by the same lane only
+            for (int i = 0; i < NEWTON_ROWS; ++i) sh.xs[ROLE - 1][i][lane] = col[(size_t)((i / 5) * NS + 4 * (i % 5)) * TILE_PAT];      // read back by the same lane only
             const int pf = p_begin + 64 * (ROLE - 1) + lane;
             sw = 0.0; ss = 0.0;
             if (pf < p_end) { sw = r.weight[pf]; ss = (double)r.scl[pf]; }
         } else {
 #pragma unroll
-            for (int i = 0; i < NEWTON_ROWS; ++i) xr[i] = col[(size_t)i * TILE_PAT];
+            for (int i = 0; i < NEWTON_ROWS; ++i) xr[i] = col[(size_t)((i / 5) * NS + 4 * (i % 5)) * TILE_PAT];
         }
     };
     if (REG && !SEQ) load_slice(wg);
@@ -722,10 +952,8 @@ __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, con
             double f = 0.0, f1 = 0.0, f2 = 0.0;
 #pragma unroll
             for (int i = 0; i < NEWTON_ROWS; ++i) {
-                const int row = sub * NEWTON_ROWS + i;
-                const double x = SVC ? sh.xs[ROLE - 1][i][lane] : xr[i];
-                const double xe = x * sh.exl[row][0], xl = xe * sh.exl[row][1];
-                f += xe; f1 += xl; f2 += xl * sh.exl[row][1];
+                const int row = row_of(i);
+                newton_term(SVC ? sh.xs[ROLE - 1][i][lane] : xr[i], sh.exl[row][0], sh.exl[row][1], f, f1, f2);
                 if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // at most 4 LDS pairs in flight
             }
             f = quad_sum(f); f1 = quad_sum(f1); f2 = quad_sum(f2);
@@ -733,20 +961,17 @@ __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, con
             // fit beside the 40 sumtable registers at 8 waves per SIMD)
             if (sub == 0) { sh.fb[0][tid >> 2] = f; sh.fb[1][tid >> 2] = f1; sh.fb[2][tid >> 2] = f2; }
         } else {
+            // streaming form (slices of more than 128 patterns): a thread owns whole patterns, rows in index order
             double acc[3] = {0.0, 0.0, 0.0};
             for (int p = p_begin + tid; p < p_end; p += NEWTON_THREADS) {
                 const double w = r.weight[p];
                 if (w == 0.0) continue;
                 double f = 0.0, f1 = 0.0, f2 = 0.0;
 #pragma unroll 8
-                for (int row = 0; row < CLV_ROWS; ++row) {
-                    const double xe = r.sumtab[clv_index(row, p)] * sh.exl[row][0], xl = xe * sh.exl[row][1];
-                    f += xe; f1 += xl; f2 += xl * sh.exl[row][1];
-                }
-                const double r1 = f1 / f;
-                acc[0] += w * (log(f * 0.25) - r.scl[p] * LOG_2_256);
-                acc[1] += w * r1;
-                acc[2] += w * (f2 / f - r1 * r1);
+                for (int row = 0; row < CLV_ROWS; ++row) newton_term(r.sumtab[clv_index(row, p)], sh.exl[row][0], sh.exl[row][1], f, f1, f2);
+                double a0, a1, a2;
+                newton_finish(f, f1, f2, w, (double)r.scl[p], a0, a1, a2);
+                acc[0] += a0; acc[1] += a1; acc[2] += a2;
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) { const double sm = wave_sum(acc[i]); if (lane == 0) sh.red[i][wave] = sm; }
@@ -757,8 +982,7 @@ __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, con
             double a0 = 0.0, a1 = 0.0, a2 = 0.0;
             if (sw != 0.0) {
                 const int j = 64 * (ROLE - 1) + lane;
-                const double f = sh.fb[0][j], r1 = sh.fb[1][j] / f;
-                a0 = sw * (log(f * 0.25) - ss * LOG_2_256); a1 = sw * r1; a2 = sw * (sh.fb[2][j] / f - r1 * r1);
+                newton_finish(sh.fb[0][j], sh.fb[1][j], sh.fb[2][j], sw, ss, a0, a1, a2);
             }
             tot[0] = wave_sum(a0); tot[1] = wave_sum(a1); tot[2] = wave_sum(a2);
             if (ROLE == 1 && lane == 0) { sh.red[0][0] = tot[0]; sh.red[1][0] = tot[1]; sh.red[2][0] = tot[2]; }
@@ -780,7 +1004,7 @@ __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, con
         }
     };
 
-    auto eval_at = [&](double t, double &L, double &d1, double &d2) {
+    auto eval_at = [&](double t, double &L, double &d1, double &d2) -> bool {
         if (SVC) fill_exl(t);
         __syncthreads();
         double tot[3] = {0.0, 0.0, 0.0};
@@ -797,76 +1021,20 @@ __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, con
                 if (SEQ) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) tot[i] = wave_sum(lane < S ? sh.part[i][lane] : 0.0);      // the split form's tree
-                } else {
-                    const u64 want = (u64)(nevals + 1);
-                    u64 *slot = gran + (size_t)((nevals & 1) * NEWTON_MAX_SPLIT) * 6;
-                    if (lane < 6) {              // publish: six granules {tag, half of a double}, one lane each
-                        const int c = lane >> 1;
-                        const u64 bits = (u64)__double_as_longlong(c == 0 ? tot[0] : (c == 1 ? tot[1] : tot[2]));
-                        st_granule(slot + wg * 6 + lane, (want << 32) | ((lane & 1) ? (bits >> 32) : (bits & 0xFFFFFFFFull)));
-                    }
-                    u64 x[6] = {0, 0, 0, 0, 0, 0};
-                    const long long t_start = wall_clock64();
-                    unsigned polls = 0;
-                    for (;;) {                   // gather: lane l re-reads slice l's granules until all six carry this evaluation's tag
-                        bool ok = true;
-                        if (lane < S) {
-#pragma unroll
-                            for (int k = 0; k < 6; ++k) { x[k] = ld_granule(slot + lane * 6 + k); ok = ok && (x[k] >> 32) == want; }
-                        }
-                        if (__all(ok)) break;
-                        __builtin_amdgcn_s_sleep(1);
-                        // bounded in wall-clock time; a slice that gives up takes the whole launch (and the stream's later
-                        // launches) with it through the abort word, so the device drains instead of spinning bound after bound
-                        if ((++polls & 63u) == 0u || timeout_ticks == 0) {
-                            if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { bad = true; break; }
-                            if (wall_clock64() - t_start > timeout_ticks) {
-                                __hip_atomic_store(&ctl->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                bad = true; break;
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {   // lanes >= S contribute +0.0 (exact); fixed shuffle tree: a function of S alone
-                        const u64 bits = ((x[2 * i + 1] & 0xFFFFFFFFull) << 32) | (x[2 * i] & 0xFFFFFFFFull);
-                        tot[i] = wave_sum(lane < S ? __longlong_as_double((long long)bits) : 0.0);
-                    }
-                }
+                } else bad = newton_exchange(gran, S, wg, nevals, r.tag_base, tot, ctl, timeout_ticks);
             }
             if (lane == 0) { sh.bc[0] = tot[0]; sh.bc[1] = tot[1]; sh.bc[2] = tot[2]; if (bad) sh.bc[3] = 1.0; }
         }
         __syncthreads();
-        if (sh.bc[3] != 0.0) failed = true;
         ++nevals;
         L = uni(sh.bc[0]); d1 = uni(sh.bc[1]); d2 = uni(sh.bc[2]);
+        return sh.bc[3] == 0.0;
     };
 
-    double t = r.t0;
-    if (r.max_iter > 0) t = t < PML_TMIN ? PML_TMIN : (t > PML_TMAX ? PML_TMAX : t);
-    t = uni(t);
-    double L = 0.0, d1 = 0.0, d2 = 0.0, tn = t;
-    bool first = true;
-    int it = 0, bt = 0;
-    for (;;) {                                          // one evaluation site: initial point, Newton steps and backtracks
-        double Ln, n1, n2;
-        eval_at(tn, Ln, n1, n2);
-        if (first) { first = false; L = Ln; d1 = n1; d2 = n2; }
-        else {
-            if (!(failed || Ln >= L - 1e-9 || bt >= 8)) { ++bt; tn = 0.5 * (tn + t); tn = uni(tn < PML_TMIN ? PML_TMIN : (tn > PML_TMAX ? PML_TMAX : tn)); continue; }
-            if (failed || Ln < L - 1e-9) break;
-            const double dt = fabs(tn - t);
-            t = tn; L = Ln; d1 = n1; d2 = n2; ++it;
-            if (dt < r.tol) break;
-        }
-        if (it >= r.max_iter || failed) break;
-        const double step = (d2 < 0.0) ? -d1 / d2 : (d1 > 0.0 ? t : -0.5 * t);
-        tn = t + step; bt = 0;
-        const bool tiny = fabs(step) < r.tol && d2 < 0.0;   // converged: take the (sub-tolerance) step unevaluated
-        tn = uni(tn < PML_TMIN ? PML_TMIN : (tn > PML_TMAX ? PML_TMAX : tn));
-        if (tiny) { t = tn; break; }
-    }
+    double t, L, d1, d2;
+    const bool ok = newton_drive(r.t0, r.max_iter, r.tol, eval_at, t, L, d1, d2);
     if (ROLE == 2 && lane == 0 && wg == 0) {
-        if (failed) { t = r.t0; L = __builtin_nan(""); }      // exchange gave up: reported, the host re-issues the request (SEQ form)
+        if (!ok) { t = r.t0; L = __builtin_nan(""); }      // exchange gave up: reported, the host re-issues the request (SEQ form)
         r.out[0] = t; r.out[1] = L; r.out[2] = d1; r.out[3] = d2;
         if (r.t_dev0) { *r.t_dev0 = t; *r.t_dev1 = t; }
     }
@@ -880,7 +1048,7 @@ __device__ __forceinline__ void newton_body(const ModelDev *__restrict__ md, con
                 if (SEQ) load_slice(s);
                 double f = 0.0;
 #pragma unroll
-                for (int i = 0; i < NEWTON_ROWS; ++i) f += (SVC ? sh.xs[ROLE - 1][i][lane] : xr[i]) * sh.exl[sub * NEWTON_ROWS + i][0];
+                for (int i = 0; i < NEWTON_ROWS; ++i) f += (SVC ? sh.xs[ROLE - 1][i][lane] : xr[i]) * sh.exl[row_of(i)][0];
                 f = quad_sum(f);
                 if (sub == 0) sh.fb[0][tid >> 2] = f;
                 __syncthreads();
@@ -921,7 +1089,11 @@ __global__ __launch_bounds__(NEWTON_THREADS, (REG && !SEQ) ? 8 : 4) void k_newto
         if (!SEQ && __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) sh.bc[3] = 2.0;
     }
     __syncthreads();
-    const int ticket = sh.ticket;
+    int ticket = sh.ticket;
+    if (!SEQ && (unsigned)ticket >= gridDim.x) {      // cannot happen with armed counters; never index the tables with it
+        if (threadIdx.x == 0) __hip_atomic_store(&ctl->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     const NewtonReq &r = reqs[ticket_req[ticket]];    // by reference: a private copy would live in scratch (rates[] is indexed dynamically)
     const int mpad = r.mpad, wg = SEQ ? 0 : ticket - r.ticket0;
     // the split depends on the request alone (not on what else is in the launch): results are reproducible
@@ -931,9 +1103,9 @@ __global__ __launch_bounds__(NEWTON_THREADS, (REG && !SEQ) ? 8 : 4) void k_newto
         if (threadIdx.x == 0 && wg == 0) { r.out[0] = r.t0; r.out[1] = __builtin_nan(""); r.out[2] = 0.0; r.out[3] = 0.0; }
     } else {
         const int wave = threadIdx.x >> 6;
-        if (wave == NEWTON_WAVES - 1) newton_body<REG, 2, SEQ>(md, r, sh, ctl, S, wg, slice, timeout_ticks);
-        else if (wave == NEWTON_WAVES - 2) newton_body<REG, 1, SEQ>(md, r, sh, ctl, S, wg, slice, timeout_ticks);
-        else newton_body<REG, 0, SEQ>(md, r, sh, ctl, S, wg, slice, timeout_ticks);
+        if (wave == NEWTON_WAVES - 1) newton_body<REG, 2, SEQ>(r, sh, ctl, S, wg, slice, timeout_ticks);
+        else if (wave == NEWTON_WAVES - 2) newton_body<REG, 1, SEQ>(r, sh, ctl, S, wg, slice, timeout_ticks);
+        else newton_body<REG, 0, SEQ>(r, sh, ctl, S, wg, slice, timeout_ticks);
     }
     if (!SEQ) {                                   // the workgroup that finishes last re-arms the ticket counter for the stream's next launch
         __syncthreads();
@@ -1066,8 +1238,11 @@ static int oplist_variant() {
     if (v < 0) { const char *e = getenv("PML_OPLIST_VARIANT"); v = e ? atoi(e) : 1; }
     return v;
 }
-void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, bool any_pitch, bool chained, hipStream_t s) {
+static long long newton_timeout_ticks();
+void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, bool any_pitch, bool chained, hipStream_t s, NewtonCtl *ctl) {
     if (nruns <= 0) return;
+    if (ctl) chained = true;                             // fused Newton tails exist in the chained variant only (k_oplist<15>)
+    const long long to = newton_timeout_ticks();
     const int bpg = (max_mpad + PAT_PER_WG - 1) / PAT_PER_WG;
     const dim3 grid((unsigned)(((nruns + 7) / 8) * 8 * bpg)), block(256);
     int v = oplist_variant();
@@ -1075,25 +1250,31 @@ void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad
     if (chained) {                                       // the descriptors carry OPF_CHAIN_* flags: only these variants honour them
         static const int cv = std::getenv("PML_CHAIN_VARIANT") ? std::atoi(std::getenv("PML_CHAIN_VARIANT")) : 11;
         v = cv == 9 ? 9 : 11;
+        if (ctl) v = 15;
     }
     const bool dbuf = (v == 2 || v == 3);
     size_t lds = (size_t)((dbuf ? 4 : 2) + (any_pitch ? 1 : 0)) * PFRAG * sizeof(double) + 512;   // 38.9 KB with pitchforks: 4 per CU
-    if (v == 11) {
+    if (v == 11 || v == 15) {
         lds = (size_t)6 * PFRAG * sizeof(double) + 512;      // 77.3 KB: two workgroups per CU, which is what its 256 VGPRs allow anyway
-        static const hipError_t big11 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_oplist<11>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (big11 != hipSuccess) {                           // no 77 KB of dynamic LDS: the single-buffered chained variant (25.6-38.4 KB) does the same work
+        static const hipError_t big11 = [&] {
+            const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void *>(k_oplist<11>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void *>(k_oplist<15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            return a != hipSuccess ? a : b;
+        }();
+        if (big11 != hipSuccess && v == 11) {                // no 77 KB of dynamic LDS: the single-buffered chained variant (25.6-38.4 KB) does the same work
             v = 9; lds = (size_t)(2 + (any_pitch ? 1 : 0)) * PFRAG * sizeof(double) + 512;
         }
     }
     const int ap = any_pitch ? 1 : 0;
     switch (v) {
-        case 0: hipLaunchKernelGGL(k_oplist<0>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
-        case 2: hipLaunchKernelGGL(k_oplist<2>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
-        case 3: hipLaunchKernelGGL(k_oplist<3>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
-        case 5: hipLaunchKernelGGL(k_oplist<5>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
-        case 9: hipLaunchKernelGGL(k_oplist<9>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
-        case 11: hipLaunchKernelGGL(k_oplist<11>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
-        default: hipLaunchKernelGGL(k_oplist<1>, grid, block, lds, s, ops, runs, nruns, bpg, ap); break;
+        case 0: hipLaunchKernelGGL(k_oplist<0>, grid, block, lds, s, ops, runs, nruns, bpg, ap, ctl, to); break;
+        case 2: hipLaunchKernelGGL(k_oplist<2>, grid, block, lds, s, ops, runs, nruns, bpg, ap, ctl, to); break;
+        case 3: hipLaunchKernelGGL(k_oplist<3>, grid, block, lds, s, ops, runs, nruns, bpg, ap, ctl, to); break;
+        case 5: hipLaunchKernelGGL(k_oplist<5>, grid, block, lds, s, ops, runs, nruns, bpg, ap, ctl, to); break;
+        case 9: hipLaunchKernelGGL(k_oplist<9>, grid, block, lds, s, ops, runs, nruns, bpg, ap, ctl, to); break;
+        case 11: hipLaunchKernelGGL(k_oplist<11>, grid, block, lds, s, ops, runs, nruns, bpg, ap, ctl, to); break;
+        case 15: hipLaunchKernelGGL(k_oplist<15>, grid, block, lds, s, ops, runs, nruns, bpg, ap, ctl, to); break;
+        default: hipLaunchKernelGGL(k_oplist<1>, grid, block, lds, s, ops, runs, nruns, bpg, ap, ctl, to); break;
     }
 }
 void launch_reduce(const ReduceReq *reqs, int n, hipStream_t s) {

@@ -191,7 +191,7 @@ int Batch::nni_round(const std::vector<char> &active, std::vector<double> &lnl, 
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipSetDevice(ctx->device));
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-        size_t budget = std::max(tailpool_cap, (size_t)(0.6 * (double)(free_b + tailpool_cap)));
+        size_t budget = std::max(tailpool_cap, (size_t)(0.6 * (double)(free_b / (size_t)std::max(share, 1) + tailpool_cap)));
         if (const char *e = std::getenv("PML_NNI_POOL_MB")) budget = (size_t)std::atoll(e) << 20;      // test hook
         if (need_all > budget) chunk = std::max<size_t>(1, budget / std::max<size_t>(per_edge, 1));
         if (int rc = ensure_tailpool(std::min(need_all, chunk * per_edge))) return rc;

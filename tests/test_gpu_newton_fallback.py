@@ -35,6 +35,16 @@ def test_giveup_falls_back_to_the_no_exchange_form_with_identical_bits():
             assert forced[key] == normal[key], key
 
 
+def test_fused_newton_has_the_bits_of_the_unfused_form():
+    """kernels.h OPF_FUSED_NEWTON: a smoothing step's branch Newton iterated inside k_oplist<15> on the register-resident
+    sumtable tile against PML_NO_FUSE=1 (sumtable stored, k_newton on it): every result bit for bit -- the unfused form is the
+    fused one's fallback, so the two must be interchangeable at any step"""
+    fused = _run({})
+    unfused = _run({"PML_NO_FUSE": "1"})
+    for key in fused:
+        assert fused[key] == unfused[key], key
+
+
 def test_two_contexts_search_concurrently_in_one_process(gpu_ctx):
     """two contexts (two streams) of ONE process searching at the same time: both succeed and each gene gets the bits of a
     lone search -- the layout whose spinning slices could starve each other under the old in-grid-order assumption"""
