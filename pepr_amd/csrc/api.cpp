@@ -279,20 +279,25 @@ static int oneshot_on(Ctx &c, int op, int n, const pml_alignment *alns, const ch
 static Ctx *worker_ctx(pml_ctx *ctx, int k) {
     while ((int)ctx->workers.size() <= k) {
         std::unique_ptr<Ctx> w(new Ctx());
-        if (w->init(ctx->c.device, false)) { ctx->c.last_error = w->last_error; return nullptr; }
+        if (w->init_worker(ctx->c)) { ctx->c.last_error = w->last_error; return nullptr; }
         ctx->workers.push_back(std::move(w));
     }
     return ctx->workers[k].get();
 }
 static int search_groups(int n, const pml_alignment *alns) {
-    // OFF by default (PML_GROUPS=1): measured on one box (gpurun_out/r3d_groups.txt), 4 groups of 32 C3 genes searched at 138
-    // gene-trees/s against 162 undivided -- hipFree / hipMalloc synchronise the whole DEVICE of a process, so the groups'
-    // buffer growth and the parsimony starts serialise them, which separate processes do not suffer
-    static const int env = std::getenv("PML_GROUPS") ? std::atoi(std::getenv("PML_GROUPS")) : 1;
-    (void)alns;
-    int g = std::max(1, std::min(env, 8));
-    while (g > 1 && n / g < 8) --g;               // a group below ~8 genes no longer fills the device's latency gaps
-    return g;
+    // PML_GROUPS overrides (1 = undivided).  Default: as many groups (<= 2) as keep >= 32 genes each, and only for genes of at
+    // most 16 tiles (2048 patterns): the groups' fused-Newton kernels run side by side, and an XCD is only GUARANTEED room for 32
+    // of their workgroups -- each group's newest, partially staffed gene must fit next to the others' (kernels.hip launch_oplist).
+    // Measured (C3, 128 genes, gpurun_out/r3j_groups.txt): 1 group 171 gene-trees/s (RAxML path 74), 2 groups 195 (97), 3 groups
+    // 215 (95); the groups' streams are of the highest priority class (their own pool of hardware queues).
+    static const int env = std::getenv("PML_GROUPS") ? std::atoi(std::getenv("PML_GROUPS")) : 0;
+    int maxcols = 0;
+    for (int i = 0; i < n; ++i) maxcols = std::max(maxcols, alns[i].nsites);
+    const int tiles = (maxcols + 127) / 128;
+    int g = env > 0 ? std::min(env, 8) : 2;                // two by default: 3 measured 179-215 from run to run, 2 stays at 195-200
+    if (env <= 0) { while (g > 1 && n / g < 32) --g; }
+    while (g > 1 && tiles * g > 32) --g;
+    return std::max(g, 1);
 }
 
 static int oneshot_chunk(pml_ctx *ctx, int op, int n, const pml_alignment *alns, const char *const *newicks,

@@ -35,11 +35,35 @@ int Ctx::init(int dev, bool prof) {
     device = dev; profile = prof;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    // the second lane's stream exists only when the lanes experiment is on (PML_LANES=1): HIP multiplexes a process's streams
+    // onto a few hardware queues, and an idle stream per context would cost the search groups (api.cpp) a queue each
+    if (std::getenv("PML_LANES")) HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    else stream2 = stream;
+    return 0;
+}
+int Ctx::init_worker(const Ctx &parent) {
+    Ctx *ctx = this;
+    device = parent.device; profile = false;
+    HIPCHK(hipSetDevice(device));
+    // A stream of the HIGHEST priority class: HIP keeps a separate pool of hardware queues per priority, so the groups' streams
+    // do not end up multiplexed onto a queue with each other's or the application's normal-priority streams (measured: two
+    // groups on one hardware queue search 150 C3 gene-trees/s, on two queues 200, one undivided batch 175).
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
+    if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi) != hipSuccess) HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    stream2 = stream;
+    return 0;
+}
+int Ctx::sync(hipStream_t s) {
+    Ctx *ctx = this;
+    if (!ev_sync) HIPCHK(hipEventCreateWithFlags(&ev_sync, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev_sync, s));
+    HIPCHK(hipEventSynchronize(ev_sync));
     return 0;
 }
 void Ctx::destroy() {
     hipSetDevice(device);
+    if (ev_sync) { hipEventDestroy(ev_sync); ev_sync = nullptr; }
     for (auto &e : pending) { pool.push_back(e.a); pool.push_back(e.b); }
     pending.clear();
     for (auto e : pool) hipEventDestroy(e);
@@ -47,8 +71,8 @@ void Ctx::destroy() {
     for (int i = 0; i < 2; ++i) { if (d_model[i]) hipFree(d_model[i]); if (d_eigfrags[i]) hipFree(d_eigfrags[i]); d_model[i] = nullptr; d_eigfrags[i] = nullptr; }
     if (arena_cache) hipFree(arena_cache);
     arena_cache = nullptr; arena_cache_bytes = 0;
-    if (stream) hipStreamDestroy(stream);
-    if (stream2) hipStreamDestroy(stream2);
+    if (stream && owns_stream) hipStreamDestroy(stream);
+    if (stream2 && stream2 != stream && owns_stream) hipStreamDestroy(stream2);
     stream = stream2 = nullptr;
 }
 int Ctx::ensure_model(int pm) {
@@ -66,7 +90,7 @@ int Ctx::ensure_model(int pm) {
     HIPCHK(hipMalloc(&d_eigfrags[pm], sizeof(double) * 2 * PFRAG));
     HIPCHK(hipMemcpy(d_model[pm], &h, sizeof h, hipMemcpyHostToDevice));
     launch_eigfrags(d_model[pm], d_eigfrags[pm], stream);
-    HIPCHK(hipStreamSynchronize(stream));
+    if (int rc = sync(stream)) return rc;
     model_ready[pm] = true;
     return 0;
 }
@@ -227,7 +251,7 @@ int Batch::layout(double alpha, bool score_only) {
     HIPCHK(hipMalloc((void **)&d_scalars, sizeof(double) * scalars_doubles));
     HIPCHK(hipHostMalloc((void **)&h_scalars, sizeof(double) * scalars_doubles, hipHostMallocDefault));
     std::memset(h_scalars, 0, sizeof(double) * scalars_doubles);
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    { if (int rc_ = ctx->sync(ctx->stream)) return rc_; }
     if (std::getenv("PML_TRACE")) fprintf(stderr, "[pml] layout: arena %.1f GiB allocated + uploaded in %.1f ms\n", (double)total / (1 << 30), now_ms() - t_alloc0);
     return 0;
 }
@@ -295,7 +319,7 @@ int GeneStore::create(Ctx *c, int n, const pml_alignment_view *alns) {
         HIPCHK(hipMemcpyAsync(it.d_codes, it.aln.codes.data(), (size_t)it.aln.ntax * it.aln.mpad, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(it.d_w, it.aln.weight.data(), (size_t)it.aln.mpad * 8, hipMemcpyHostToDevice, ctx->stream));
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    { if (int rc_ = ctx->sync(ctx->stream)) return rc_; }
     return 0;
 }
 void GeneStore::destroy() { if (arena) { hipSetDevice(ctx->device); hipFree(arena); arena = nullptr; } items.clear(); }
@@ -360,7 +384,7 @@ int Batch::create_replicates(Ctx *c, const GeneStore &store, const std::vector<s
     hipError_t e1 = hipMemcpyAsync(d_buf, hs.data(), hs.size() * sizeof(GatherSeg), hipMemcpyHostToDevice, ctx->stream);
     hipError_t e2 = hipMemcpyAsync((char *)d_buf + seg_bytes, rowmaps.data(), map_bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e1 == hipSuccess && e2 == hipSuccess) launch_gather((const GatherSeg *)d_buf, (int)hs.size(), max_npat, ctx->stream);
-    hipError_t e3 = hipStreamSynchronize(ctx->stream);
+    hipError_t e3 = ctx->sync(ctx->stream) ? hipErrorUnknown : hipSuccess;
     hipFree(d_buf);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return ctx->fail(-4, "replicate gather failed");
     return 0;
@@ -375,10 +399,10 @@ int Batch::fetch_results(bool pooled) {
 }
 int Batch::chain_sync() {
     if (int rc = flush_deferred()) return rc;
-    if (lanes_active) HIPCHK(hipStreamSynchronize(ctx->stream2));      // lane 1's results must be complete before the copy
+    if (lanes_active) { if (int rc_ = ctx->sync(ctx->stream2)) return rc_; }      // lane 1's results must be complete before the copy
     if (int rc = fetch_results(true)) return rc;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream2));
+    { if (int rc_ = ctx->sync(ctx->stream)) return rc_; }
+    { if (int rc_ = ctx->sync(ctx->stream2)) return rc_; }
     HIPCHK(hipGetLastError());
     ctx->resolve_events();
     chain_off = 0;
@@ -563,14 +587,22 @@ static double now_ms() {
 
 void Batch::newton_gave_up() {
     ++ctx->newton_giveups;
+    if (std::getenv("PML_TRACE") && d_nctl) {
+        NewtonCtl h[2];
+        if (hipMemcpy(h, d_nctl, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[pml] k_newton exchange gave up: slice %d of %d, evaluation %d, arrived mask %08x%08x, tickets taken in its partition %d, (left * 1024 + partition) %d; tickets %d %d done %d %d oticket %d %d %d %d %d %d %d %d odone %d\n",
+                    h[0].dbg[1], h[0].dbg[2], h[0].dbg[3], (unsigned)h[0].dbg[5], (unsigned)h[0].dbg[4], (unsigned)h[0].dbg[6], h[0].dbg[7], h[0].ticket[0], h[0].ticket[1], h[0].done[0], h[0].done[1],
+                    h[0].oticket[0], h[0].oticket[1], h[0].oticket[2], h[0].oticket[3], h[0].oticket[4], h[0].oticket[5], h[0].oticket[6], h[0].oticket[7], h[0].odone);
+        hipMemset(&d_nctl[0].dbg[0], 0, sizeof(int));
+    }
     safe_left = safe_hold; safe_hold = std::min(safe_hold * 2, 1024);
 }
 // the sticky abort word of both lanes' control blocks back to 0 (ordered on the batch's streams, then waited for)
 int Batch::clear_abort() {
     if (!d_nctl) return 0;
     for (int l = 0; l < 2; ++l) HIPCHK(hipMemsetAsync(&d_nctl[l].abort, 0, sizeof(int), l ? ctx->stream2 : ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream2));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    { if (int rc_ = ctx->sync(ctx->stream2)) return rc_; }
+    { if (int rc_ = ctx->sync(ctx->stream)) return rc_; }
     return 0;
 }
 
@@ -655,7 +687,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         HIPCHK(hipMalloc((void **)&nsync_buf, cap * NEWTON_SYNC_DOUBLES * sizeof(double)));
         // granule tags are (launch number << 10) + evaluation: a fresh block must not hold a matching tag by accident
         HIPCHK(hipMemsetAsync(nsync_buf, 0, cap * NEWTON_SYNC_DOUBLES * sizeof(double), ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        { if (int rc_ = ctx->sync(ctx->stream)) return rc_; }
         nsync_c = cap;
     }
     if (nnewton && !d_nctl) {
@@ -664,7 +696,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         // non-blocking streams the kernels use -- landing inside the first k_newton it would re-issue tickets and leave the
         // counters un-armed for the next launch (seen as time-outs and a memory fault when several batches shared the device)
         HIPCHK(hipMemsetAsync(d_nctl, 0, 2 * sizeof(NewtonCtl), ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        { if (int rc_ = ctx->sync(ctx->stream)) return rc_; }
     }
     const hipStream_t st = lane ? ctx->stream2 : ctx->stream;
     double *const frags_buf = lane ? d_frags2 : d_frags;
@@ -920,9 +952,12 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
                 pm[c] = add_req(g, o.t[c], PM_FRAGS, bv, bq);
             }
             // the child that is the gene's previous result goes LEFT (the two factors of a newview commute bit for bit)
-            if (chained_from(o.child[1], S[1].kind)) { std::swap(S[0], S[1]); std::swap(pm[0], pm[1]); std::swap(o.child[0], o.child[1]); }
+            // (the PendingOp itself keeps its order: t[], bv[], bq[] belong to its children by position, and a launch set that has to
+            // be issued again -- run()'s retry in safe mode -- must find it unchanged)
+            Side ch[2] = {o.child[0], o.child[1]};
+            if (chained_from(ch[1], S[1].kind)) { std::swap(S[0], S[1]); std::swap(pm[0], pm[1]); std::swap(ch[0], ch[1]); }
             d.flags = S[0].kind | (S[1].kind << 2);
-            if (chained_from(o.child[0], S[0].kind)) { d.flags |= OPF_CHAIN_L; consume_last(); }
+            if (chained_from(ch[0], S[0].kind)) { d.flags |= OPF_CHAIN_L; consume_last(); }
             d.l = S[0].s; d.r = S[1].s; d.l_scl = S[0].scl; d.r_scl = S[1].scl; d.pl = pm[0]; d.pr = pm[1];
             algo_bytes += (double)G.aln.npat * (S[0].bytes + S[1].bytes + 640);
             algo_flops += (double)G.aln.npat * ((S[0].inner && S[1].inner ? 6480 : (S[0].inner || S[1].inner ? 3280 : 80)) + S[0].flops + S[1].flops);
@@ -992,7 +1027,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         bool pooled = false;
         for (auto &t : tails) pooled = pooled || t.result_host != nullptr;
         if (int rc = fetch_results(pooled)) return rc;
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        { if (int rc_ = ctx->sync(ctx->stream)) return rc_; }
         HIPCHK(hipGetLastError());
         const double t_done = now_ms();
         ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += t_done - t_launched;
@@ -1031,7 +1066,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             launch_newton_seq(ctx->d_model[pi_mode], (const NewtonReq *)(ds + o_newt), (const int *)(ds + o_tick), nr, ns, d_nctl + lane, ctx->stream);
             ++ctx->newton_seq_launches;
             if (int rc = fetch_results(pooled)) return rc;
-            HIPCHK(hipStreamSynchronize(ctx->stream));
+            { if (int rc_ = ctx->sync(ctx->stream)) return rc_; }
             HIPCHK(hipGetLastError());
         }
         for (auto &t : tails) {
@@ -1099,7 +1134,7 @@ int Batch::replay_plan(double *lnl) {
     ctx->stats[K_HOST_BUILD].launches++; ctx->stats[K_HOST_BUILD].ms += t_launched - t_begin;
     if (!chain) {
         if (int rc = fetch_results(false)) return rc;
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        { if (int rc_ = ctx->sync(ctx->stream)) return rc_; }
         HIPCHK(hipGetLastError());
         const double t_done = now_ms();
         ctx->stats[K_HOST_WAIT].launches++; ctx->stats[K_HOST_WAIT].ms += t_done - t_launched;
@@ -1364,7 +1399,7 @@ int Batch::gamma20(std::vector<double> &lnl20, std::vector<double> &alpha20, std
         launch_g20((const G20Req *)d_stage, k, ctx->stream);
         results_used = (size_t)n;
         if (int rc = fetch_results(true)) return rc;
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        { if (int rc_ = ctx->sync(ctx->stream)) return rc_; }
         HIPCHK(hipGetLastError());
         for (int g : who) { f[g] = -h_chain[4 * g]; if (!std::isfinite(f[g])) return ctx->fail(-5, "device returned a non-finite Gamma20 likelihood"); }
         return 0;

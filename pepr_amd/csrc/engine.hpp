@@ -37,6 +37,12 @@ struct Ctx {
     char *arena_cache = nullptr; size_t arena_cache_bytes = 0;
 
     int init(int dev, bool prof);
+    // a worker context of a grouped search call (api.cpp): its own stream (highest priority class: its own pool of hardware
+    // queues), events, statistics and arena cache
+    int init_worker(const Ctx &parent);
+    bool owns_stream = true;
+    hipEvent_t ev_sync = nullptr;
+    int sync(hipStream_t s);             // wait for everything THIS context has enqueued on s so far (event-based: other users of a shared stream may enqueue behind it)
     void destroy();
     int ensure_model(int pi_mode);
     hipEvent_t get_event();

@@ -242,12 +242,27 @@ __device__ __forceinline__ bool newton_exchange(u64 *gran, int S, int wg, int ne
             for (int k = 0; k < 6; ++k) { x[k] = ld_granule(slot + lane * 6 + k); ok = ok && (x[k] >> 32) == want; }
         }
         if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(1);
+        // Back-off: a partner that is only a few microseconds behind (the normal case) is met by the first, dense polls; a slice
+        // whose partners have not even STARTED (more workgroups than slots: they start when an earlier gene finishes, tens of
+        // microseconds later) must not keep hammering the fabric meanwhile -- agent-scope loads bypass the caches, and a few
+        // hundred waves polling back to back slowed the running genes down to the point of a time-out (16 genes of 200 x 5000:
+        // 25 of a gene's 39 tiles resident and spinning next to a fully staffed gene)
+        ++polls;
+        if (polls < 16u) __builtin_amdgcn_s_sleep(1);
+        else if (polls < 32u) __builtin_amdgcn_s_sleep(8);
+        else if (polls < 64u) __builtin_amdgcn_s_sleep(32);
+        else __builtin_amdgcn_s_sleep(127);
         // bounded in wall-clock time; a slice that gives up takes the whole launch (and the stream's later launches) with it
         // through the abort word, so the device drains instead of spinning bound after bound
-        if ((++polls & 63u) == 0u || timeout_ticks == 0) {
+        if ((polls & 15u) == 0u || timeout_ticks == 0) {
             if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { bad = true; break; }
             if (wall_clock64() - t_start > timeout_ticks) {
+                const unsigned long long have = __ballot(ok);
+                if (lane == 0 && atomicCAS(&ctl->dbg[0], 0, 1) == 0) {
+                    ctl->dbg[1] = wg; ctl->dbg[2] = S; ctl->dbg[3] = nevals; ctl->dbg[4] = (int)(have & 0xFFFFFFFFull); ctl->dbg[5] = (int)(have >> 32);
+                    ctl->dbg[6] = __hip_atomic_load(&ctl->oticket[blockIdx.x & 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ctl->dbg[7] = __hip_atomic_load(&ctl->odone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 1024 + (int)(blockIdx.x & 7);
+                }
                 __hip_atomic_store(&ctl->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 bad = true; break;
             }
@@ -732,8 +747,11 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : (VARIANT >= 8) ? PML_CHAI
     // an XCD and its L2), so all pattern blocks of one gene get the same blockIdx % 8: the gene's
     // transition-matrix fragments are then fetched into ONE L2 instead of eight (speed only).
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int xcd = blockIdx.x & 7;
-    int slot = blockIdx.x >> 3;
+    // blocks_per_gene < 0 (ticketed launches of genes too large for two of them per XCD): ONE partition, genes in plain order
+    const bool one_part = blocks_per_gene < 0;
+    if (one_part) blocks_per_gene = -blocks_per_gene;
+    const int xcd = one_part ? 0 : (blockIdx.x & 7);
+    int slot = one_part ? (int)blockIdx.x : (int)(blockIdx.x >> 3);
     // Launches with fused Newton tails (ctl != null): the gene's workgroups exchange sums, i.e. WAIT for each other, so the
     // slot is not tied to blockIdx but claimed by ticket when the workgroup starts (one counter per XCD partition, which keeps
     // a gene's tiles on one XCD): whoever holds a ticket is running, and so are the holders of all lower tickets of the
@@ -757,7 +775,7 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : (VARIANT >= 8) ? PML_CHAI
             }
         }
     };
-    const int gi = xcd + 8 * (slot / blocks_per_gene), blk = slot % blocks_per_gene;
+    const int gi = one_part ? slot / blocks_per_gene : xcd + 8 * (slot / blocks_per_gene), blk = slot % blocks_per_gene;
     if (gi >= nruns) { leave(); return; }
     const GeneRun run = runs[gi];
     if (run.op_begin >= run.op_end) { leave(); return; }
@@ -1239,12 +1257,38 @@ static int oplist_variant() {
     return v;
 }
 static long long newton_timeout_ticks();
+static void launch_oplist_one(const NvOp *ops, const GeneRun *runs, int nruns, int bpg, bool one_part, bool any_pitch, bool chained, hipStream_t s, NewtonCtl *ctl);
 void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, bool any_pitch, bool chained, hipStream_t s, NewtonCtl *ctl) {
     if (nruns <= 0) return;
-    if (ctl) chained = true;                             // fused Newton tails exist in the chained variant only (k_oplist<15>)
-    const long long to = newton_timeout_ticks();
     const int bpg = (max_mpad + PAT_PER_WG - 1) / PAT_PER_WG;
-    const dim3 grid((unsigned)(((nruns + 7) / 8) * 8 * bpg)), block(256);
+    if (!ctl) { launch_oplist_one(ops, runs, nruns, bpg, false, any_pitch, chained, s, nullptr); return; }
+    // Launches with fused Newton tails: the workgroups of a gene WAIT for each other.  Slots are claimed by ticket per XCD
+    // (workgroup b runs on XCD b % 8: tools/ubench_xcc.hip), so on every XCD all genes but the newest are fully staffed, and the
+    // newest needs room for its missing tiles on THAT XCD.  An XCD holds 64 of these workgroups at best (32 CUs x 2: 77 KB of
+    // LDS each, and only when the allocator packs a CU's two without a hole) but always 32 (one per CU).  Measured with
+    // tools/ubench_ticket.hip: gangs of up to 32 never stall however oversubscribed the launch; gangs of 35 / 40 stall now and
+    // then, gangs of 63 always -- and 16 genes of 200 x 5000 (35 tiles each) did in the engine.  Hence:
+    //   bpg <= 32: ONE launch, however many genes (C3: 128 genes x 8 tiles on 512 slots);
+    //   bpg  > 32: the gene list is cut into launches that are resident as a whole on the idle device (<= cap / bpg genes, one
+    //              ticket partition), so that no workgroup ever waits for one that has not been dispatched.
+    if (bpg <= 32) { launch_oplist_one(ops, runs, nruns, bpg, false, any_pitch, true, s, ctl); return; }
+    static const int cap = [] {
+        int dev = 0, cus = 256, nb = 2; hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        const size_t lds15 = (size_t)6 * PFRAG * sizeof(double) + 512;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_oplist<15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds15);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k_oplist<15>), 256, lds15) != hipSuccess || nb < 1) nb = 1;
+        if (nb > 2) nb = 2;                                  // 256 VGPRs: two waves per SIMD whatever the query says
+        return cus * nb;
+    }();
+    const int genes_per_launch = std::max(1, cap / bpg);
+    for (int off = 0; off < nruns; off += genes_per_launch)
+        launch_oplist_one(ops, runs + off, std::min(genes_per_launch, nruns - off), bpg, true, any_pitch, true, s, ctl);
+}
+static void launch_oplist_one(const NvOp *ops, const GeneRun *runs, int nruns, int bpg_in, bool one_part, bool any_pitch, bool chained, hipStream_t s, NewtonCtl *ctl) {
+    const long long to = newton_timeout_ticks();
+    const int bpg = one_part ? -bpg_in : bpg_in;
+    const dim3 grid((unsigned)(one_part ? nruns * bpg_in : ((nruns + 7) / 8) * 8 * bpg_in)), block(256);
     int v = oplist_variant();
     if (any_pitch && (v == 2 || v == 3)) v = 1;          // pitchfork regions are not combined with double buffering
     if (chained) {                                       // the descriptors carry OPF_CHAIN_* flags: only these variants honour them

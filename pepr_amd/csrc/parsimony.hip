@@ -180,7 +180,7 @@ static int fitch_step(Ctx *ctx, Stage &st, Stage &sc, const std::vector<PGene *>
     PCHK(hipGetLastError());
     std::vector<int> flat(nsc);
     if (nsc) PCHK(hipMemcpyAsync(flat.data(), d_out, nsc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    PCHK(hipStreamSynchronize(ctx->stream));
+    if (int rc_ = ctx->sync(ctx->stream)) return rc_;
     scores.assign(nr, {});
     ps = 0;
     for (size_t i = 0; i < nr; ++i) { scores[i].assign(flat.begin() + ps, flat.begin() + ps + nscores[i]); ps += nscores[i]; }

@@ -151,7 +151,7 @@ int Batch::sh_support(int nboot, unsigned long long seed, std::vector<std::vecto
         HIPCHK(hipMemcpyAsync(d_req, hreq.data(), sizeof(ShReq) * who.size(), hipMemcpyHostToDevice, ctx->stream));
         launch_sh(d_req, (int)who.size(), ctx->stream);
         HIPCHK(hipMemcpyAsync(hout.data(), d_out, sizeof(double) * who.size(), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        { if (int rc_ = ctx->sync(ctx->stream)) return rc_; }
         for (size_t i = 0; i < who.size(); ++i) support[who[i]][step] = hout[i];
     }
     return 0;
