@@ -238,6 +238,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true", help="skip the gene-trees/s leg (NJ + NNI search of every gene)")
     ap.add_argument("--no-c4", action="store_true", help="skip the c4_shard / c4_strong record (also BENCH_NO_C4=1)")
+    ap.add_argument("--no-stored", action="store_true", help="skip the stored-traversal leg (counter passes: every k_oplist launch of the run is then of one kind)")
+    ap.add_argument("--stored-only", action="store_true", help="every scoring step of the run is the stored traversal (counter passes of that leg)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--genes", type=int, default=0, help="strong scaling: total genes of the job (default 500 for c4, 128 for c3, 16 for tiny)")
     args = ap.parse_args()
@@ -324,7 +326,7 @@ def main():
             rec_ids = [ids[i] for i in idx] + [-1] * (len(chunks[0]) - len(idx))     # equal record counts per rank
 
             def step(stored=False):
-                return batch.score(stored) if batch else np.zeros(0)          # ends with the results on this rank's host (synchronised)
+                return batch.score(stored or args.stored_only) if batch else np.zeros(0)          # ends with the results on this rank's host (synchronised)
 
             def gather(lnls):
                 # THE one gather of per-gene results of a job (RCCL over xGMI): the K passes of the timed region are
@@ -358,7 +360,7 @@ def main():
             # untimed step, repeated until clock_warmup_s have passed; `value` is the steady state behind it, `cold` the K steps before
             t_w = time.perf_counter()
             while ci == 0 and batch and time.perf_counter() - t_w < clock_warmup_s:
-                batch.score(); res["clock_warmup_steps"] += 1          # no collective here: every rank loops on its own clock
+                step(); res["clock_warmup_steps"] += 1          # no collective here: every rank loops on its own clock
             if ci == 0:
                 ctx.kernel_stats(reset=True)
             d, out = timed(steps)
@@ -389,7 +391,7 @@ def main():
         return res
 
     ctx = engine.Context(local, profile=True)
-    S = score_legs(ctx, genes, gene_ids, args.steps, args.warmup, float(os.environ.get("BENCH_CLOCK_WARMUP_S", "1.5")), True)
+    S = score_legs(ctx, genes, gene_ids, args.steps, args.warmup, float(os.environ.get("BENCH_CLOCK_WARMUP_S", "1.5")), not (args.no_stored or args.stored_only))
     ctx.close()
     nchunks, npat, tot_pat, dt = S["nchunks"], S["npat"], S["npat_all"], S["dt"]
 

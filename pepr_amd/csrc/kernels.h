@@ -179,6 +179,8 @@ void launch_eigfrags(const ModelDev *model, double *frags2, hipStream_t s);
 // any_pitch: some op has an SK_PITCH side (two more LDS fragment regions are allocated)
 // ctl != null: the launch has fused Newton tails (OPF_FUSED_NEWTON): chained variant, (gene, tile) claimed by ticket
 void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, bool any_pitch, bool chained, hipStream_t s, NewtonCtl *ctl = nullptr);
+// workgroups of the fused-Newton op-list kernel the idle device holds at once (2 per CU)
+int fused_oplist_capacity();
 void launch_reduce(const ReduceReq *reqs, int n, hipStream_t s);
 // tickets: request index per ticket, register-form tickets [0, nreg) then streaming-form [nreg, nreg + nstream)
 void launch_newton(const ModelDev *model, const NewtonReq *reqs, const int *tickets, int nreg, int nstream, NewtonCtl *ctl, hipStream_t s);

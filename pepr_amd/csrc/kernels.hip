@@ -1258,6 +1258,7 @@ static int oplist_variant() {
 }
 static long long newton_timeout_ticks();
 static void launch_oplist_one(const NvOp *ops, const GeneRun *runs, int nruns, int bpg, bool one_part, bool any_pitch, bool chained, hipStream_t s, NewtonCtl *ctl);
+int fused_oplist_capacity();
 void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, bool any_pitch, bool chained, hipStream_t s, NewtonCtl *ctl) {
     if (nruns <= 0) return;
     const int bpg = (max_mpad + PAT_PER_WG - 1) / PAT_PER_WG;
@@ -1272,6 +1273,12 @@ void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad
     //   bpg  > 32: the gene list is cut into launches that are resident as a whole on the idle device (<= cap / bpg genes, one
     //              ticket partition), so that no workgroup ever waits for one that has not been dispatched.
     if (bpg <= 32) { launch_oplist_one(ops, runs, nruns, bpg, false, any_pitch, true, s, ctl); return; }
+    const int cap = fused_oplist_capacity();
+    const int genes_per_launch = std::max(1, cap / bpg);
+    for (int off = 0; off < nruns; off += genes_per_launch)
+        launch_oplist_one(ops, runs + off, std::min(genes_per_launch, nruns - off), bpg, true, any_pitch, true, s, ctl);
+}
+int fused_oplist_capacity() {
     static const int cap = [] {
         int dev = 0, cus = 256, nb = 2; hipDeviceProp_t p;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
@@ -1281,9 +1288,7 @@ void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad
         if (nb > 2) nb = 2;                                  // 256 VGPRs: two waves per SIMD whatever the query says
         return cus * nb;
     }();
-    const int genes_per_launch = std::max(1, cap / bpg);
-    for (int off = 0; off < nruns; off += genes_per_launch)
-        launch_oplist_one(ops, runs + off, std::min(genes_per_launch, nruns - off), bpg, true, any_pitch, true, s, ctl);
+    return cap;
 }
 static void launch_oplist_one(const NvOp *ops, const GeneRun *runs, int nruns, int bpg_in, bool one_part, bool any_pitch, bool chained, hipStream_t s, NewtonCtl *ctl) {
     const long long to = newton_timeout_ticks();
