@@ -181,6 +181,18 @@ def git_head():
         return None
 
 
+def committed_pmc_stored(workload):
+    """the same for the stored traversal (its own counter passes: bench.py --stored-only)"""
+    out = {"traffic": None, "traffic_source": None, "traffic_commit": None, "pipe_busy": None, "pipe_busy_source": None}
+    f = os.path.join(ROOT, "profiles", "r03_pmc_k_oplist_stored_%s.json" % workload)
+    if os.path.exists(f):
+        d = json.load(open(f))
+        out["traffic"] = d["derived"].get("hbm_traffic_GB") and d["derived"]["hbm_traffic_GB"] * 1e9
+        out["traffic_source"] = "committed PMC passes, profiles/" + os.path.basename(f); out["traffic_commit"] = d.get("commit")
+        out["pipe_busy"] = d["derived"].get("mfma_pipe_busy_frac"); out["pipe_busy_source"] = "profiles/%s @ %s" % (os.path.basename(f), d.get("commit"))
+    return out
+
+
 def committed_pmc(workload):
     """HBM bytes per k_oplist launch and matrix-pipe busy share from the COMMITTED rocprofv3 --pmc passes of this same command
     (separate passes per counter group, tools/pmc_collect.sh; counters cannot be read from inside the run).  Every file
@@ -214,9 +226,8 @@ def roofline_of(nv, pmc, upper_bound_flops, stored=False):
     ach = flops / sec / 1e12 if sec > 0 else 0.0
     r = {"bound": "mfma", "kernel": "k_oplist (newview + evaluate)", "achieved": ach, "peak": PEAK_F64_MATRIX_TFLOPS, "unit": "TFLOP/s",
          "frac": ach / PEAK_F64_MATRIX_TFLOPS, "avg_launch_ms": avg_ms, "algo_flops_per_launch": flops,
-         "traffic": None if stored else pmc["traffic"], "traffic_source": None if stored else pmc["traffic_source"],
-         "traffic_commit": None if stored else pmc["traffic_commit"],
-         "matrix_pipe_busy_frac_pmc": None if stored else pmc["pipe_busy"], "matrix_pipe_busy_source": None if stored else pmc["pipe_busy_source"],
+         "traffic": pmc["traffic"], "traffic_source": pmc["traffic_source"], "traffic_commit": pmc["traffic_commit"],
+         "matrix_pipe_busy_frac_pmc": pmc["pipe_busy"], "matrix_pipe_busy_source": pmc["pipe_busy_source"],
          "survey_8d_closed_form": {"flops_per_launch": upper_bound_flops, "note": "6480 (n-2) + 3360 flop per site-lnL, 8d's upper bound ignoring tip savings; NOT what the kernel executes",
                                    "tflops": upper_bound_flops / sec / 1e12 if sec > 0 else 0.0},
          # the HBM side: 8d's per-operation bytes of the op list (what an unfused traversal would move) next to what the
@@ -224,8 +235,8 @@ def roofline_of(nv, pmc, upper_bound_flops, stored=False):
          # chip's 8 TB/s -- it is an accounting figure, not a transfer rate, and carries no `frac`
          "hbm": {"algorithmic_bytes_per_launch": algo_bytes, "algorithmic_GB_per_s": algo_bytes / sec / 1e9 if sec > 0 else 0.0,
                  "peak_GB_per_s": PEAK_HBM_GBS,
-                 "traffic_GB_per_s": (pmc["traffic"] / sec / 1e9) if (pmc["traffic"] and sec > 0 and not stored) else None,
-                 "traffic_frac_of_peak": (pmc["traffic"] / sec / 1e9 / PEAK_HBM_GBS) if (pmc["traffic"] and sec > 0 and not stored) else None}}
+                 "traffic_GB_per_s": (pmc["traffic"] / sec / 1e9) if (pmc["traffic"] and sec > 0) else None,
+                 "traffic_frac_of_peak": (pmc["traffic"] / sec / 1e9 / PEAK_HBM_GBS) if (pmc["traffic"] and sec > 0) else None}}
     return r
 
 
@@ -486,7 +497,7 @@ def main():
             # (later partial traversals read them back); same lnL bits (asserted above)
             out["stored_traversal"] = {"value": tot_pat * args.steps / S["dt_stored"] / 1e6, "unit": "M site-lnL/s",
                                        "ms_per_step": S["dt_stored"] / args.steps * 1e3,
-                                       "roofline": roofline_of(S["stats_stored"]["newview"], pmc, upper, stored=True),
+                                       "roofline": roofline_of(S["stats_stored"]["newview"], committed_pmc_stored(args.workload) if not strong else committed_pmc("none"), upper, stored=True),
                                        "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in S["stats_stored"].items() if v["launches"]}}
         if search is not None:
             out["search"] = search
