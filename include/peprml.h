@@ -72,12 +72,17 @@ typedef struct {
     const char *const *rows;    /* ntax rows of nsites chars */
 } pml_alignment;
 
-enum { PML_PI_RAXML_3DP = 0, PML_PI_WAG_FULL = 1 };
+/* PML_PI_EMPIRICAL = RAxML's "F" models (PROTGAMMAWAGF, one of the names -matrix_eval passes, PhylogenomicPipeline2.java:260-284;
+ * RAxMLRunner's own default is an F model, RAxMLRunner.java:46): WAG exchangeabilities with frequencies counted from each
+ * gene's alignment (eight sweeps of proportional counting, ambiguity codes spread over their states, floor 0.001) -- a
+ * per-gene eigen-system.  Built for score / optimize / search / per-site calls and resident batches; the jackknife's
+ * device-gathered replicates refuse it. */
+enum { PML_PI_RAXML_3DP = 0, PML_PI_WAG_FULL = 1, PML_PI_EMPIRICAL = 2 };
 
 typedef struct {
     int ncat;                /* Gamma categories (4 = RAxML PROTGAMMA; 1 = no rate heterogeneity) */
     double alpha;            /* Gamma shape (start value when optimised) */
-    int pi_mode;             /* PML_PI_RAXML_3DP (RAxML 7.2.5 PROTGAMMAWAG) or PML_PI_WAG_FULL */
+    int pi_mode;             /* PML_PI_RAXML_3DP (RAxML 7.2.5 PROTGAMMAWAG), PML_PI_WAG_FULL (FastTree_WAG) or PML_PI_EMPIRICAL (PROTGAMMAWAGF) */
 } pml_model;
 
 typedef struct {

@@ -102,13 +102,60 @@ static void jacobi20(double A[PO_NS][PO_NS], double d[PO_NS], double V[PO_NS][PO
     }
 }
 
+/* PROTGAMMAWAGF (RAxMLRunner.java:46 default PROTGAMMALGF, PhylogenomicPipeline2.java:260-284 -matrix_eval names): the "F"
+ * models replace the matrix's own frequencies by EMPIRICAL ones counted from the alignment.  Restated from RAxML's published
+ * scheme (parity unpinned: no source, no fixture in the reference): start from 1/20 each; eight sweeps in which every
+ * character of every taxon spreads its pattern weight over the states it allows in proportion to the current frequencies
+ * (an unambiguous residue counts 1 for its state, B = N|D and Z = Q|E share theirs, gap / ? / X spread over all 20, i.e. add
+ * nothing but a multiple of the current vector); normalise after every sweep; finally states rarer than 0.001 are lifted to
+ * 0.001 and the others scaled down so that the sum stays 1 (repeated until none is below). */
+void po_empirical_freqs(const po_aln *a, double *pi) {
+    double f[20], acc[20];
+    for (int l = 0; l < 20; l++) f[l] = 0.05;
+    for (int sweep = 0; sweep < 8; sweep++) {
+        for (int l = 0; l < 20; l++) acc[l] = 0.0;
+        for (int i = 0; i < a->ntax; i++) for (int p = 0; p < a->npat; p++) {
+            const unsigned mk = po_code_mask(a->codes[(size_t)i * a->npat + p]);
+            double sum = 0.0;
+            for (int l = 0; l < 20; l++) if ((mk >> l) & 1) sum += f[l];
+            const double wj = (double)a->weight[p] / sum;
+            for (int l = 0; l < 20; l++) if ((mk >> l) & 1) acc[l] += wj * f[l];
+        }
+        double tot = 0.0;
+        for (int l = 0; l < 20; l++) tot += acc[l];
+        for (int l = 0; l < 20; l++) f[l] = acc[l] / tot;
+    }
+    for (int round = 0; round < 100; round++) {
+        double lift = 0.0, big = 0.0; int low = 0;
+        for (int l = 0; l < 20; l++) { if (f[l] < 0.001) { lift += 0.001 - f[l]; low++; } else big += f[l]; }
+        if (!low) break;
+        for (int l = 0; l < 20; l++) f[l] = f[l] < 0.001 ? 0.001 : f[l] * (1.0 - lift / big);
+    }
+    for (int l = 0; l < 20; l++) pi[l] = f[l];
+}
+
+static void model_from_pi(po_model *m, double S[PO_NS][PO_NS]);
+void po_model_init_freqs(po_model *m, const double *pi) {
+    double S[PO_NS][PO_NS], pf[PO_NS], p3[PO_NS];
+    po_wag_tables(S, pf, p3);
+    double sum = 0;
+    for (int i = 0; i < 20; i++) { m->pi[i] = pi[i]; sum += pi[i]; }
+    for (int i = 0; i < 20; i++) m->pi[i] /= sum;
+    model_from_pi(m, S);
+}
 void po_model_init(po_model *m, int pi_mode) {
-    double S[PO_NS][PO_NS], pf[PO_NS], p3[PO_NS], B[PO_NS][PO_NS], V[PO_NS][PO_NS];
-    int i, j;
+    double S[PO_NS][PO_NS], pf[PO_NS], p3[PO_NS];
+    int i;
     po_wag_tables(S, pf, p3);
     double sum = 0;
     for (i = 0; i < 20; i++) { m->pi[i] = (pi_mode == PO_PI_FULL) ? pf[i] : p3[i]; sum += m->pi[i]; }
     for (i = 0; i < 20; i++) m->pi[i] /= sum;
+    model_from_pi(m, S);
+}
+/* Q = S diag(pi) normalised to one substitution per site, symmetrised eigen-decomposition (m->pi is set and sums to 1) */
+static void model_from_pi(po_model *m, double S[PO_NS][PO_NS]) {
+    double B[PO_NS][PO_NS], V[PO_NS][PO_NS];
+    int i, j;
     double mu = 0;
     for (i = 0; i < 20; i++) {
         double row = 0;

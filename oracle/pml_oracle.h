@@ -62,6 +62,8 @@ typedef struct {
 /* ---- model ---- */
 void po_wag_tables(double S[PO_NS][PO_NS], double pi_full[PO_NS], double pi_3dp[PO_NS]);
 void po_model_init(po_model *m, int pi_mode);
+/* PROTGAMMAWAGF: WAG exchangeabilities with the given (empirical) frequencies; po_empirical_freqs counts them from an alignment */
+void po_model_init_freqs(po_model *m, const double *pi20);
 void po_pmatrix(const po_model *m, double t, double P[PO_NS][PO_NS]);
 double po_lngamma(double x);
 double po_incgamma(double a, double x);             /* regularised lower P(a,x) */
@@ -74,6 +76,7 @@ int po_char_code(int c);
 po_aln *po_aln_create(int ntax, int nsites, const char *const *names, const char *const *rows,
                       int compress);
 void po_aln_free(po_aln *a);
+void po_empirical_freqs(const po_aln *a, double *pi20);
 
 /* ---- tree ---- */
 po_tree *po_tree_parse(const char *newick, const po_aln *a, char *err, int errlen);

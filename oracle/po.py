@@ -25,6 +25,8 @@ def lib():
         vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
         L.po_model_init.argtypes = [vp, C.c_int]
         L.po_pmatrix.argtypes = [vp, C.c_double, dp]
+        L.po_model_init_freqs.argtypes = [vp, dp]
+        L.po_empirical_freqs.argtypes = [vp, dp]
         L.po_gamma_rates.argtypes = [C.c_double, C.c_int, C.c_int, dp]
         L.po_incgamma.restype = C.c_double
         L.po_incgamma.argtypes = [C.c_double, C.c_double]
@@ -92,9 +94,15 @@ PI_RAXML3DP, PI_FULL = 0, 1
 
 
 class Model:
-    def __init__(self, pi_mode=PI_RAXML3DP):
+    def __init__(self, pi_mode=PI_RAXML3DP, pi=None):
+        """pi_mode: RAxML's 3-decimal or FastTree's full-precision WAG frequencies; pi: 20 explicit frequencies instead
+        (PROTGAMMAWAGF: pass empirical_freqs(alignment))"""
         self.s = _ModelStruct()
-        lib().po_model_init(C.byref(self.s), pi_mode)
+        if pi is not None:
+            arr = np.ascontiguousarray(pi, dtype=np.float64)
+            lib().po_model_init_freqs(C.byref(self.s), arr.ctypes.data_as(C.POINTER(C.c_double)))
+        else:
+            lib().po_model_init(C.byref(self.s), pi_mode)
         self.ptr = C.cast(C.byref(self.s), C.c_void_p)
         self.pi = np.array(self.s.pi)
         self.Q = np.array(self.s.Q).reshape(20, 20)
@@ -106,6 +114,13 @@ class Model:
         out = np.zeros(400)
         lib().po_pmatrix(self.ptr, t, out.ctypes.data_as(C.POINTER(C.c_double)))
         return out.reshape(20, 20)
+
+
+def empirical_freqs(aln):
+    """RAxML "F" model frequencies of an Alignment (numpy array of 20)"""
+    out = np.zeros(20)
+    lib().po_empirical_freqs(aln.ptr, out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
 
 
 def gamma_rates(alpha, K=4, median=False):

@@ -75,17 +75,39 @@ void Ctx::destroy() {
     if (stream2 && stream2 != stream && owns_stream) hipStreamDestroy(stream2);
     stream = stream2 = nullptr;
 }
+static void fill_model_dev(const Model &m, ModelDev &h) {
+    std::memcpy(h.eval, m.eval, sizeof h.eval);
+    std::memcpy(h.U, m.U, sizeof h.U);
+    std::memcpy(h.Uinv, m.Uinv, sizeof h.Uinv);
+    std::memcpy(h.pi, m.pi, sizeof h.pi);
+    for (int k = 0; k < NS; ++k) for (int j = 0; j < NS; ++j) h.UinvT[j * NS + k] = m.Uinv[k * NS + j];
+}
+// PROTGAMMAWAGF (pi_mode 2): empirical frequencies per gene (host.cpp empirical_freqs), WAG exchangeabilities, one
+// eigen-decomposition per gene on the host (20 x 20 Jacobi), models + eigen-basis fragment sets uploaded once per batch
+int Batch::build_gene_models() {
+    const size_t n = genes.size();
+    std::vector<ModelDev> h(n);
+    for (size_t g = 0; g < n; ++g) {
+        double pi[20];
+        empirical_freqs(genes[g].aln, pi);
+        Model m; m.init_pi(pi);
+        fill_model_dev(m, h[g]);
+    }
+    HIPCHK(hipMalloc((void **)&d_gmodel, n * sizeof(ModelDev)));
+    HIPCHK(hipMalloc((void **)&d_geig, n * 2 * PFRAG * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(d_gmodel, h.data(), n * sizeof(ModelDev), hipMemcpyHostToDevice, ctx->stream));
+    launch_eigfrags_n(d_gmodel, d_geig, (int)n, ctx->stream);
+    if (int rc = ctx->sync(ctx->stream)) return rc;      // h goes out of scope
+    return 0;
+}
 int Ctx::ensure_model(int pm) {
     Ctx *ctx = this;
-    if (pm < 0 || pm > 1) return fail(-1, "bad pi_mode");
+    if (pm == 2) return 0;                  // PROTGAMMAWAGF: per-gene models live in the batch (Batch::build_gene_models)
+    if (pm < 0 || pm > 2) return fail(-1, "bad pi_mode");
     if (model_ready[pm]) return 0;
     model[pm].init(pm);
     ModelDev h;
-    std::memcpy(h.eval, model[pm].eval, sizeof h.eval);
-    std::memcpy(h.U, model[pm].U, sizeof h.U);
-    std::memcpy(h.Uinv, model[pm].Uinv, sizeof h.Uinv);
-    std::memcpy(h.pi, model[pm].pi, sizeof h.pi);
-    for (int k = 0; k < NS; ++k) for (int j = 0; j < NS; ++j) h.UinvT[j * NS + k] = model[pm].Uinv[k * NS + j];
+    fill_model_dev(model[pm], h);
     HIPCHK(hipMalloc(&d_model[pm], sizeof(ModelDev)));
     HIPCHK(hipMalloc(&d_eigfrags[pm], sizeof(double) * 2 * PFRAG));
     HIPCHK(hipMemcpy(d_model[pm], &h, sizeof h, hipMemcpyHostToDevice));
@@ -185,7 +207,8 @@ int Batch::create(Ctx *c, int n, const pml_alignment_view *alns, const char *con
         for (int g = 0; g < n; ++g) if (!errs[g].empty()) return ctx->fail(-2, "gene " + std::to_string(g) + ": " + errs[g]);
     }
     if (std::getenv("PML_TRACE")) fprintf(stderr, "[pml] create: encode + start trees of %d genes %.1f ms\n", n, now_ms() - t_create0);
-    return layout(alpha, score_only);
+    if (int rc = layout(alpha, score_only)) return rc;
+    return pm == 2 ? build_gene_models() : 0;
 }
 
 // device arena + per-gene pointers from (ntax, mpad) alone; host-encoded codes/weights are uploaded when present
@@ -270,6 +293,8 @@ void Batch::destroy() {
     if (d_frags) hipFree(d_frags);
     if (d_nsync) hipFree(d_nsync);
     if (d_nctl) { hipFree(d_nctl); d_nctl = nullptr; }
+    if (d_gmodel) { hipFree(d_gmodel); d_gmodel = nullptr; }
+    if (d_geig) { hipFree(d_geig); d_geig = nullptr; }
     if (ev_stagger) { hipEventDestroy(ev_stagger); ev_stagger = nullptr; }
     if (d_nsync2) hipFree(d_nsync2);
     if (d_frags2) hipFree(d_frags2);
@@ -330,6 +355,7 @@ int Batch::create_replicates(Ctx *c, const GeneStore &store, const std::vector<s
     virtual_pitch = virtual_cherries && std::getenv("PML_NO_PITCH") == nullptr;
     const int n = (int)sel.size();
     if (n <= 0) return ctx->fail(-1, "empty batch");
+    if (pm == 2) return ctx->fail(-1, "PROTGAMMAWAGF (empirical frequencies) is built for score / optimize / search calls, not for device-gathered replicates");
     if (int rc = ctx->ensure_model(pm)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     genes.resize(n);
@@ -615,7 +641,7 @@ int Batch::flush_deferred() {
     const size_t lo = deferred.front().base, hi = deferred.back().base + deferred.back().bytes;
     const hipStream_t cs = deferred.front().lane ? ctx->stream2 : ctx->stream;
     HIPCHK(hipMemcpyAsync((char *)d_stage + lo, (char *)h_stage + lo, hi - lo, hipMemcpyHostToDevice, cs));
-    const ModelDev *md = ctx->d_model[pi_mode];
+    const ModelDev *md = pi_mode < 2 ? ctx->d_model[pi_mode] : nullptr;      // per-gene models travel in the requests
     static const bool serialize = std::getenv("PML_SERIALIZE") != nullptr;      // diagnostic: a host sync after every launch
 #define PML_SER() do { if (serialize) hipStreamSynchronize(st); } while (0)
     if (serialize) hipStreamSynchronize(cs);
@@ -626,7 +652,7 @@ int Batch::flush_deferred() {
         ctx->tic_stream = st;
         if (L.nreq) {
             ctx->tic(K_PMAT, (double)L.nreq * PFRAG * 8);
-            launch_pmat(md, (const PmatReq *)(ds + L.o_req), frags_buf, (int)L.nreq, st);
+            launch_pmat(md, (const PmatReq *)(ds + L.o_req), frags_buf, (int)L.nreq, st, d_gmodel != nullptr);
             ctx->toc(); PML_SER();
         }
         if (L.nruns) {
@@ -743,7 +769,6 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     std::vector<char> fused_req(nnewton, 0);
     bool any_fused = false;
     std::vector<int> tail_req(ntail, -1);          // tail -> index of its NewtonReq (failure handling below)
-    const double *eig = ctx->d_eigfrags[pi_mode];
 
     size_t nout = 0, nruns = 0, ie = 0, in = 0, ireq = 0, iop = 0;
     last_src.clear();
@@ -789,6 +814,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         PmatReq &r = hreq[ireq];
         r.t = t; std::memcpy(r.rates, genes[g].rates, sizeof r.rates); r.kind = kind; r.pad = 0;
         r.tp = (chain && v >= 0 && genes[g].len_pending[(size_t)v * 3 + q]) ? genes[g].d_len + (size_t)v * 3 + q : nullptr;
+        r.md = d_gmodel ? d_gmodel + g : nullptr;
         last_src.push_back({(int)g, v, q, kind});
         const double *out = frags_buf + (ireq++) * FRAG_STRIDE;
         if (!record_plan) { if (v >= 0) { req_stamp[key] = req_launch; req_ptr[key] = out; } else bucket->push_back({tbits, out}); }
@@ -904,12 +930,12 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
                 algo_bytes += (double)G.aln.npat * (L.bytes + R.bytes + 8);
                 algo_flops += (double)G.aln.npat * (3360 + L.flops + R.flops);
             } else {
-                d.pl = eig; d.pr = eig + PFRAG;
+                d.pl = eig_of((int)g); d.pr = d.pl + PFRAG;
                 double *stab = t.sumtab_dev ? t.sumtab_dev : G.d_sumtab[t.slot];
                 int *sscl = t.sumtab_dev ? reinterpret_cast<int *>(t.sumtab_dev + clv_doubles(mp)) : G.d_sumscl[t.slot];
                 d.out = stab; d.out_scl = sscl;
                 NewtonReq &nr = hnewt[in];
-                nr.md = ctx->d_model[pi_mode]; nr.tag_base = tag_base; nr.pad0 = 0;
+                nr.md = model_of((int)g); nr.tag_base = tag_base; nr.pad0 = 0;
                 if (fuse_ok && tails_of[g].size() == 1 && t.after < 0 && !t.patlnl_dev && newton_reg_form(mp)) {
                     d.flags |= OPF_FUSED_NEWTON; d.aux = (const NewtonReq *)(ds + o_newt) + in;
                     fused_req[in] = 1; any_fused = true; any_chain = true;
@@ -1074,7 +1100,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             for (int pass = 0; pass < 2; ++pass) for (int i : bad) if (newton_reg_form(hnewt[i].mpad) == (pass == 0)) { htick[nr + ns] = i; ++(pass == 0 ? nr : ns); }
             if (int rc = clear_abort()) return rc;
             HIPCHK(hipMemcpyAsync(ds + o_tick, hs + o_tick, bad.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-            launch_newton_seq(ctx->d_model[pi_mode], (const NewtonReq *)(ds + o_newt), (const int *)(ds + o_tick), nr, ns, d_nctl + lane, ctx->stream);
+            launch_newton_seq(nullptr, (const NewtonReq *)(ds + o_newt), (const int *)(ds + o_tick), nr, ns, d_nctl + lane, ctx->stream);
             ++ctx->newton_seq_launches;
             if (int rc = fetch_results(pooled)) return rc;
             { if (int rc_ = ctx->sync(ctx->stream)) return rc_; }
@@ -1131,9 +1157,9 @@ int Batch::replay_plan(double *lnl) {
     }
     char *ds = (char *)P.d;
     if (changed) HIPCHK(hipMemcpyAsync(ds + P.o_req, hreq, P.nreq * sizeof(PmatReq), hipMemcpyHostToDevice, ctx->stream));
-    const ModelDev *md = ctx->d_model[pi_mode];
+    const ModelDev *md = pi_mode < 2 ? ctx->d_model[pi_mode] : nullptr;      // per-gene models travel in the requests
     ctx->tic(K_PMAT, (double)P.nreq * PFRAG * 8);
-    launch_pmat(md, (const PmatReq *)(ds + P.o_req), d_frags, (int)P.nreq, ctx->stream);
+    launch_pmat(md, (const PmatReq *)(ds + P.o_req), d_frags, (int)P.nreq, ctx->stream, d_gmodel != nullptr);
     ctx->toc();
     ctx->tic(K_NEWVIEW, P.algo_bytes, P.algo_flops);
     launch_oplist((const NvOp *)(ds + P.o_ops), (const GeneRun *)(ds + P.o_runs), (int)P.nruns, P.max_mpad, P.any_pitch, P.any_chain, ctx->stream);

@@ -106,6 +106,11 @@ struct PendingOp { int gene, out_kind, out_id, level; Side child[2]; double t[2]
 struct Batch {
     Ctx *ctx = nullptr;
     int pi_mode = 0, ncat = 4, det_id = 0;
+    // pi_mode 2 (PROTGAMMAWAGF): every gene has its own eigen-system from its empirical frequencies
+    ModelDev *d_gmodel = nullptr; double *d_geig = nullptr;       // [genes] models, [genes][2*PFRAG] eigen-basis fragment sets
+    const ModelDev *model_of(int g) const { return d_gmodel ? d_gmodel + g : ctx->d_model[pi_mode]; }
+    const double *eig_of(int g) const { return d_geig ? d_geig + (size_t)g * 2 * PFRAG : ctx->d_eigfrags[pi_mode]; }
+    int build_gene_models();
     int share = 1;                 // batches working on the device at the same time (groups of one search call): free HBM is divided by it
     double newton_tol = 1e-8;      // Newton stop |dt| < tol: 1e-8 fine, 1e-6 in coarse phases
     std::vector<Gene> genes;

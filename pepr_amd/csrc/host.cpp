@@ -71,12 +71,13 @@ static void sym_eig20(std::vector<double> &A, double *eval, std::vector<double> 
     V.swap(V2);
 }
 
-void Model::init(int pi_mode) {
+void Model::init(int pi_mode) { init_pi(pi_mode == 1 ? kWagPiFull : kWagPi3dp); }
+void Model::init_pi(const double *pi20) {
     double S[400] = {0};
     int k = 0;
     for (int i = 1; i < 20; ++i) for (int j = 0; j < i; ++j) { S[i * 20 + j] = S[j * 20 + i] = kWagLower[k++]; }
     double sum = 0;
-    for (int i = 0; i < 20; ++i) { pi[i] = pi_mode == 1 ? kWagPiFull[i] : kWagPi3dp[i]; sum += pi[i]; }
+    for (int i = 0; i < 20; ++i) { pi[i] = pi20[i]; sum += pi[i]; }
     for (int i = 0; i < 20; ++i) pi[i] /= sum;
     double mu = 0;
     for (int i = 0; i < 20; ++i) {
@@ -172,6 +173,33 @@ int aa_code(int ch) {
     };
     static const Table table;          // thread-safe initialisation (genes are encoded on several threads)
     return table.t[(unsigned char)ch];
+}
+
+static unsigned host_code_mask(int code) { return code < 20 ? (1u << code) : (code == 20 ? 0xCu : (code == 21 ? 0x60u : 0xFFFFFu)); }
+// PROTGAMMAWAGF: eight sweeps of proportional counting from 1/20, then a floor of 0.001 (oracle: po_empirical_freqs)
+void empirical_freqs(const EncodedAlignment &a, double *pi) {
+    double f[20], acc[20];
+    for (int l = 0; l < 20; ++l) f[l] = 0.05;
+    for (int sweep = 0; sweep < 8; ++sweep) {
+        for (int l = 0; l < 20; ++l) acc[l] = 0.0;
+        for (int i = 0; i < a.ntax; ++i) for (int p = 0; p < a.npat; ++p) {
+            const unsigned mk = host_code_mask(a.codes[(size_t)i * a.mpad + p]);
+            double sum = 0.0;
+            for (int l = 0; l < 20; ++l) if ((mk >> l) & 1) sum += f[l];
+            const double wj = a.weight[p] / sum;
+            for (int l = 0; l < 20; ++l) if ((mk >> l) & 1) acc[l] += wj * f[l];
+        }
+        double tot = 0.0;
+        for (int l = 0; l < 20; ++l) tot += acc[l];
+        for (int l = 0; l < 20; ++l) f[l] = acc[l] / tot;
+    }
+    for (int round = 0; round < 100; ++round) {
+        double lift = 0.0, big = 0.0; int low = 0;
+        for (int l = 0; l < 20; ++l) { if (f[l] < 0.001) { lift += 0.001 - f[l]; ++low; } else big += f[l]; }
+        if (!low) break;
+        for (int l = 0; l < 20; ++l) f[l] = f[l] < 0.001 ? 0.001 : f[l] * (1.0 - lift / big);
+    }
+    for (int l = 0; l < 20; ++l) pi[l] = f[l];
 }
 
 bool EncodedAlignment::encode(int nt, int ns, const char *const *nm, const char *const *rows, std::string &err) {

@@ -19,7 +19,11 @@ struct Model {
     double U[400];      // P(t) = U diag(exp(eval t)) Uinv
     double Uinv[400];
     void init(int pi_mode);
+    void init_pi(const double *pi20);    // WAG exchangeabilities with the given frequencies (PROTGAMMAWAGF)
 };
+struct EncodedAlignment;
+// empirical amino-acid frequencies, RAxML's "F" models (spec: oracle/pml_oracle.c po_empirical_freqs)
+void empirical_freqs(const EncodedAlignment &a, double *pi20);
 
 // mean rates of K equal-probability Gamma(alpha, mean 1) bins (Yang 1994); K==1 -> {1}
 void gamma_rates(double alpha, int K, double *rates);

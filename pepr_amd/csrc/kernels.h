@@ -42,6 +42,7 @@ struct PmatReq {
     int pad;
     const double *tp;       // non-null: the length is read from device memory (written by an earlier k_newton of
                             // the same stream: chained smoothing pass), `t` is ignored
+    const ModelDev *md;     // per-gene model (PROTGAMMAWAGF: empirical frequencies); null = the launch's model
 };
 enum { PM_FRAGS = 0, PM_FRAGS_PI = 1, PM_TIPTABLE = 2 };
 
@@ -172,10 +173,13 @@ void launch_gather(const GatherSeg *segs, int nsegs, int max_npat, hipStream_t s
 struct ShReq { const double *l0, *l1, *l2; const int *site2pat; double *out; unsigned long long seed; int nsites, nboot; };
 void launch_sh(const ShReq *reqs, int n, hipStream_t s);
 
-void launch_pmat(const ModelDev *model, const PmatReq *reqs, double *frags, int n, hipStream_t s);
+// per_request: the requests carry their own models (PmatReq::md), `model` is ignored
+void launch_pmat(const ModelDev *model, const PmatReq *reqs, double *frags, int n, hipStream_t s, bool per_request = false);
 // constant fragment sets for the eigen-basis transforms used by the sumtable:
 //   set 0: x_i = sum_s pi_s U[s][i] A[s]     set 1: y_i = sum_j Uinv[i][j] B[j]
 void launch_eigfrags(const ModelDev *model, double *frags2, hipStream_t s);
+// n models in an array, n x 2*PFRAG doubles out
+void launch_eigfrags_n(const ModelDev *models, double *frags2, int n, hipStream_t s);
 // any_pitch: some op has an SK_PITCH side (two more LDS fragment regions are allocated)
 // ctl != null: the launch has fused Newton tails (OPF_FUSED_NEWTON): chained variant, (gene, tile) claimed by ticket
 void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, bool any_pitch, bool chained, hipStream_t s, NewtonCtl *ctl = nullptr);

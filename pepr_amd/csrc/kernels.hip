@@ -76,7 +76,10 @@ __device__ __forceinline__ void frag_decode(int idx, int &c, int &row, int &col)
 // sum_{j in states(code)} P_c[4 kk + q][j] (the contraction of a tip's indicator vector, by lookup).
 // ------------------------------------------------------------------------------------------
 constexpr int PMAT_THREADS = 256;
-__global__ __launch_bounds__(PMAT_THREADS, 2) void k_pmat(const ModelDev *__restrict__ md,
+// PER_REQ: every request names its own model (PROTGAMMAWAGF: per-gene empirical frequencies, hence per-gene eigen-systems):
+// the lane's 50 U / Uinv operands, two eigenvalues and five frequencies are re-read (L2) for each request instead of once
+template <bool PER_REQ>
+__global__ __launch_bounds__(PMAT_THREADS, 2) void k_pmat(const ModelDev *__restrict__ md0,
                                                           const PmatReq *__restrict__ reqs,
                                                           double *__restrict__ frags, int n) {
     __shared__ double sE[PMAT_THREADS / 64][NCAT * NS];
@@ -84,20 +87,26 @@ __global__ __launch_bounds__(PMAT_THREADS, 2) void k_pmat(const ModelDev *__rest
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i4 = lane & 3, k4 = lane >> 4, cb = (lane >> 2) & 3;
     double Au[5][5], Bu[5][5];
-#pragma unroll
-    for (int a = 0; a < 5; ++a)
-#pragma unroll
-        for (int b = 0; b < 5; ++b) {
-            Au[a][b] = md->U[(4 * a + i4) * NS + 4 * b + k4];          // [st][kk]
-            Bu[a][b] = md->Uinv[(4 * a + k4) * NS + 4 * b + i4];       // [kk][nt]
-        }
+    double lam0, lam1, pi_row[5];                // D row = 4 st + (lane>>4)
     // exponentials: lane l owns table rows l and (l < 16) 64 + l; row r = category r / 20, eigenvalue r % 20
-    const double lam0 = md->eval[lane % NS], lam1 = md->eval[(64 + (lane & 15)) % NS];
     const int cat0 = lane / NS, cat1 = (64 + (lane & 15)) / NS;
-    const double pi_row[5] = {md->pi[k4], md->pi[4 + k4], md->pi[8 + k4], md->pi[12 + k4], md->pi[16 + k4]};   // D row = 4 st + (lane>>4)
+    auto load_model = [&](const ModelDev *__restrict__ md) {
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                Au[a][b] = md->U[(4 * a + i4) * NS + 4 * b + k4];          // [st][kk]
+                Bu[a][b] = md->Uinv[(4 * a + k4) * NS + 4 * b + i4];       // [kk][nt]
+            }
+        lam0 = md->eval[lane % NS]; lam1 = md->eval[(64 + (lane & 15)) % NS];
+#pragma unroll
+        for (int a = 0; a < 5; ++a) pi_row[a] = md->pi[4 * a + k4];
+    };
+    if (!PER_REQ) load_model(md0);
     const int nwaves = gridDim.x * (PMAT_THREADS / 64);
     for (int rq = blockIdx.x * (PMAT_THREADS / 64) + wv; rq < n; rq += nwaves) {
         const PmatReq &req = reqs[rq];
+        if (PER_REQ) load_model(req.md);
         const double tlen = req.tp ? *req.tp : req.t;
         const int kind = req.kind;
         double *sEw = sE[wv];
@@ -155,8 +164,10 @@ __global__ __launch_bounds__(PMAT_THREADS, 2) void k_pmat(const ModelDev *__rest
     }
 }
 
-__global__ __launch_bounds__(256) void k_eigfrags(const ModelDev *__restrict__ md,
-                                                  double *__restrict__ frags2) {
+__global__ __launch_bounds__(256) void k_eigfrags(const ModelDev *__restrict__ models,
+                                                  double *__restrict__ frags2_all) {
+    const ModelDev *__restrict__ md = models + blockIdx.x;                 // one model per workgroup
+    double *__restrict__ frags2 = frags2_all + (size_t)blockIdx.x * 2 * PFRAG;
     for (int idx = threadIdx.x; idx < PFRAG; idx += 256) {
         int c, i, s;
         frag_decode(idx, c, i, s);
@@ -1242,14 +1253,18 @@ void launch_gather(const GatherSeg *segs, int nsegs, int max_npat, hipStream_t s
     if (nsegs <= 0 || max_npat <= 0) return;
     hipLaunchKernelGGL(k_gather, dim3((unsigned)nsegs, (unsigned)((max_npat + 255) / 256)), dim3(256), 0, s, segs);
 }
-void launch_pmat(const ModelDev *model, const PmatReq *reqs, double *frags, int n, hipStream_t s) {
+void launch_pmat(const ModelDev *model, const PmatReq *reqs, double *frags, int n, hipStream_t s, bool per_request) {
     if (n <= 0) return;
     const int per_block = PMAT_THREADS / 64;                  // one wave per request, persistent beyond 2 waves per SIMD
     const int blocks = std::min((n + per_block - 1) / per_block, 512);
-    hipLaunchKernelGGL(k_pmat, dim3(blocks), dim3(PMAT_THREADS), 0, s, model, reqs, frags, n);
+    if (per_request) hipLaunchKernelGGL(k_pmat<true>, dim3(blocks), dim3(PMAT_THREADS), 0, s, model, reqs, frags, n);
+    else hipLaunchKernelGGL(k_pmat<false>, dim3(blocks), dim3(PMAT_THREADS), 0, s, model, reqs, frags, n);
 }
 void launch_eigfrags(const ModelDev *model, double *frags2, hipStream_t s) {
     hipLaunchKernelGGL(k_eigfrags, dim3(1), dim3(256), 0, s, model, frags2);
+}
+void launch_eigfrags_n(const ModelDev *models, double *frags2, int n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_eigfrags, dim3((unsigned)n), dim3(256), 0, s, models, frags2);
 }
 static int oplist_variant() {
     static int v = -1;

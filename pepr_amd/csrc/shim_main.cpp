@@ -159,10 +159,12 @@ int main(int argc, char **argv) {
         else return fail(tool, "unknown option " + a);
     }
     if (aln_f.empty() || run.empty()) return fail(tool, "usage: raxmlHPC -f d|e|g -m PROTGAMMAWAG -s aln.phy -n run [-t tree] [-z trees]");
-    // exactly one model is built; PROTGAMMAWAGF (empirical frequencies), PROTCATWAG, PROTGAMMAIWAG and the other 22
-    // matrices -matrix_eval may pass (PhylogenomicPipeline2.java:260-284) are different likelihood functions and are
-    // refused rather than run as WAG under their name
-    if (model_s != "PROTGAMMAWAG") return fail(tool, "only -m PROTGAMMAWAG is built, got " + model_s);
+    // two models are built: PROTGAMMAWAG and PROTGAMMAWAGF (the same exchangeabilities with frequencies counted from the
+    // alignment); PROTCATWAG, PROTGAMMAIWAG and the other matrices -matrix_eval may pass (PhylogenomicPipeline2.java:260-284:
+    // their tables are not in the reference) are different likelihood functions and are refused rather than run as WAG
+    // under their name
+    if (model_s != "PROTGAMMAWAG" && model_s != "PROTGAMMAWAGF") return fail(tool, "only -m PROTGAMMAWAG and PROTGAMMAWAGF are built, got " + model_s);
+    const int pi_mode_s = model_s == "PROTGAMMAWAGF" ? PML_PI_EMPIRICAL : PML_PI_RAXML_3DP;
     if (std::ifstream("RAxML_info." + run)) return fail(tool, "RAxML output files with the run ID <" + run + "> already exist");
     if (f == "b") {                                       // RAxMLRunner.java:453-516: draw the bipartition frequencies of -z trees on -t tree (host only)
         if (tree_f.empty() || trees_f.empty()) return fail(tool, "-f b needs -t tree -z trees");
@@ -188,7 +190,7 @@ int main(int argc, char **argv) {
     pml_ctx *ctx = nullptr; pml_config cfg = {0, 0, 0};
     if (int rc = pml_create(&cfg, &ctx)) return fail(tool, std::string("engine: ") + pml_strerror(rc) + " " + pml_last_error(nullptr));
     std::vector<const char *> np, rp; pml_alignment v = view(a, np, rp);
-    pml_model model = {4, 1.0, PML_PI_RAXML_3DP};
+    pml_model model = {4, 1.0, pi_mode_s};
     std::ofstream info("RAxML_info." + run), logf("RAxML_log." + run);
     info << "peprml raxmlHPC shim (MI355X HIP engine), model " << model_s << ", alignment " << aln_f << "\n";
     int rc = 0;
@@ -248,7 +250,7 @@ int main(int argc, char **argv) {
             pml_result o, r;
             rc = pml_optimize(ctx, &v, trees[i].c_str(), &model, &opts, &o);     // -f g optimises model + lengths per tree
             if (rc) break;
-            pml_model m2 = {4, o.alpha, PML_PI_RAXML_3DP};
+            pml_model m2 = {4, o.alpha, pi_mode_s};
             rc = pml_score(ctx, &v, o.newick, &m2, PML_WANT_SITE_LNL, &r);
             if (!rc) {
                 out << "tr" << (i + 1) << "\t";

@@ -10,7 +10,7 @@ from . import _lib
 
 KERNELS = {"pmat": 0, "newview": 1, "evaluate": 2, "sumtable": 3, "newton": 4, "reduce": 5,
            "host_build": 6, "host_wait": 7}
-PI_RAXML_3DP, PI_WAG_FULL = 0, 1
+PI_RAXML_3DP, PI_WAG_FULL, PI_EMPIRICAL = 0, 1, 2      # PI_EMPIRICAL = PROTGAMMAWAGF (frequencies counted per gene)
 
 
 class PmlError(RuntimeError):

@@ -49,13 +49,16 @@ class SequenceAlignment:
 
 def _model_from_matrix(matrix):
     """RAxML -m strings PEPR passes (RAxMLRunner.java:115-132; the 23 names of -matrix_eval,
-    PhylogenomicPipeline2.java:260-284).  Exactly ONE model is built -- PROTGAMMAWAG (WAG exchangeabilities, RAxML's
-    fixed 3-decimal WAG frequencies, GAMMA with 4 mean-rate categories) -- and nothing else is ever run under another
-    model's name: PROTGAMMAWAGF (empirical frequencies), PROTCATWAG, PROTGAMMAIWAG and the other matrices raise."""
+    PhylogenomicPipeline2.java:260-284).  TWO models are built -- PROTGAMMAWAG (WAG exchangeabilities, RAxML's
+    3-decimal frequencies, Gamma4) and PROTGAMMAWAGF (the same with frequencies counted from the alignment) -- and a
+    likelihood is never reported under another model's name: PROTCATWAG, PROTGAMMAIWAG and the other matrices (whose
+    tables the reference does not hold) raise."""
     m = (matrix or "PROTGAMMAWAG").upper()
+    if m == "PROTGAMMAWAGF":
+        return {"ncat": 4, "pi_mode": engine.PI_EMPIRICAL}
     if m != "PROTGAMMAWAG":
-        raise ValueError("the GPU engine implements PROTGAMMAWAG only; %r is not built (it would be a different "
-                         "likelihood function, not a variant spelling)" % matrix)
+        raise ValueError("the GPU engine implements PROTGAMMAWAG and PROTGAMMAWAGF only; %r is not built (it would be a "
+                         "different likelihood function, not a variant spelling)" % matrix)
     return {"ncat": 4, "pi_mode": engine.PI_RAXML_3DP}
 
 

@@ -78,3 +78,47 @@ def test_incgamma_quantile_roundtrip(oracle_lib):
             x = L.po_gamma_quantile(p, a)
             assert abs(L.po_incgamma(a, x) - p) < 1e-12
             assert abs(gammainc(a, x) - p) < 1e-10
+
+
+def test_empirical_frequencies_wagf(oracle_lib):
+    """PROTGAMMAWAGF (PhylogenomicPipeline2.java:260-284; RAxMLRunner.java:46): frequencies counted from the alignment.
+    Without ambiguity codes the proportional counting is plain counting; gaps / X pull the sweeps towards the counts of the
+    informative characters (they spread over the current vector); B / Z split between their two states in proportion; rare states are floored at 0.001; the model built
+    from them is a proper reversible rate matrix with one substitution per site."""
+    po = oracle_lib
+    import numpy as np
+    from pepr_amd import synth
+    names, rows, nw = synth.simulate_alignment(9, 500, 21)
+    a = po.Alignment(names, rows)
+    f = po.empirical_freqs(a)
+    txt = "".join(rows)
+    cnt = np.array([txt.count(c) for c in synth.AA], float)
+    assert abs(f.sum() - 1) < 1e-12 and np.abs(f - cnt / cnt.sum()).max() < 1e-12
+    # gaps, '?' and X are uninformative
+    rows2 = [r[:100] + "-" * 50 + "?" * 30 + "X" * 20 + r[200:] for r in rows]
+    a2 = po.Alignment(names, rows2)
+    txt2 = "".join(r[:100] + r[200:] for r in rows)
+    cnt2 = np.array([txt2.count(c) for c in synth.AA], float)
+    assert np.abs(po.empirical_freqs(a2) - cnt2 / cnt2.sum()).max() < 1e-6      # eight sweeps: geometric convergence, not equality
+    # B = N|D: a column of B's shifts N and D only, in their current proportion
+    rows3 = [r + "B" * 40 for r in rows]
+    f3 = po.empirical_freqs(po.Alignment(names, rows3))
+    iN, iD = synth.AA.index("N"), synth.AA.index("D")
+    others = [i for i in range(20) if i not in (iN, iD)]
+    assert f3[iN] > f[iN] and f3[iD] > f[iD] and abs(f3[iN] / f3[iD] - f[iN] / f[iD]) < 0.02
+    assert np.abs(f3[others] / f3[others].sum() - f[others] / f[others].sum()).max() < 1e-9
+    # floor: an alignment that lacks most amino acids
+    f4 = po.empirical_freqs(po.Alignment(["a", "b", "c"], ["AAAAARRRRR", "AAAAARRRRN", "AAAARRRRRR"]))
+    assert abs(f4.sum() - 1) < 1e-12 and f4.min() >= 0.001 - 1e-15 and (f4 < 0.0011).sum() == 17
+    # the model: detailed balance, rows of Q sum to 0, mean rate 1, P(t) stochastic with stationary distribution pi
+    m = po.Model(pi=f)
+    assert np.abs(m.pi - f).max() < 1e-15
+    assert np.abs(m.Q.sum(1)).max() < 1e-12 and abs(-(m.pi * np.diag(m.Q)).sum() - 1) < 1e-12
+    assert np.abs(m.pi[:, None] * m.Q - (m.pi[:, None] * m.Q).T).max() < 1e-14
+    P = m.pmatrix(0.37)
+    assert np.abs(P.sum(1) - 1).max() < 1e-12 and np.abs(m.pi @ P - m.pi).max() < 1e-12
+    # and the likelihood it gives equals the independent numpy pruning with the same frequencies
+    import util
+    t = po.Tree(nw, a)
+    ref, _ = util.numpy_lnl(names, rows, nw, 0.7, pi_mode=f)
+    assert abs(po.Engine(a, m, 4, 0.7).lnl(t) - ref) < 1e-8 * abs(ref)

@@ -17,11 +17,13 @@ def test_dispatch_and_errors_cpu():
     assert tb._model_from_matrix("PROTGAMMAWAG")["ncat"] == 4
     # -matrix_eval (PhylogenomicPipeline2.java:260-284) compares lnL across model names: a name that is not built must
     # never be run as plain WAG under its label
-    for other in ("PROTGAMMAWAGF", "PROTCATWAG", "PROTGAMMAIWAG", "PROTGAMMALGF", "PROTGAMMAJTT", "PROTMIXWAG"):
+    from pepr_amd import engine
+    assert tb._model_from_matrix("PROTGAMMAWAGF") == {"ncat": 4, "pi_mode": engine.PI_EMPIRICAL}      # the F variant IS built
+    for other in ("PROTCATWAG", "PROTGAMMAIWAG", "PROTGAMMALGF", "PROTGAMMAJTT", "PROTMIXWAG", "PROTGAMMAWAGFX"):
         with pytest.raises(ValueError):
             tb._model_from_matrix(other)
     r = tb.RAxMLRunner()
-    r.setAlignment(tb.SequenceAlignment(["a", "b", "c"], ["AR", "AR", "AQ"])); r.setMatrix("PROTGAMMAWAGF")
+    r.setAlignment(tb.SequenceAlignment(["a", "b", "c"], ["AR", "AR", "AQ"])); r.setMatrix("PROTGAMMALGF")
     with pytest.raises(ValueError):
         r.run()                                   # refused before anything touches the device
     b.setBootstrapReps(0); assert b.getBootstrapReps() == 0

@@ -42,7 +42,7 @@ def parse_newick(nw):
 def numpy_lnl(names, rows, newick, alpha, pi_mode="raxml", ncat=4):
     """Per-site lnL by pruning in numpy with log-space normalisation. Returns (total, per-site)."""
     S, pi_full, pi_3 = synth.wag_constants()
-    pi = (pi_3 if pi_mode == "raxml" else pi_full)
+    pi = np.asarray(pi_mode, float) if not isinstance(pi_mode, str) else (pi_3 if pi_mode == "raxml" else pi_full)    # or 20 explicit frequencies
     pi = pi / pi.sum()
     lam, U, Uinv = synth._eig(pi)
     rates = synth.gamma_mean_rates(alpha, ncat) if ncat > 1 else np.ones(1)
