@@ -841,6 +841,238 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : (VARIANT >= 8) ? PML_CHAI
 }
 
 // ------------------------------------------------------------------------------------------
+// k_oplist16 (round 3): the chained op-list kernel with ONE pattern per lane -- a wave owns 16 patterns instead of 32.
+// Why: k_oplist<11> needs 256 VGPRs (the chained result alone is 80), i.e. 2 waves per SIMD, and its MFMA bursts are separated
+// by L2 / HBM round trips that two waves cannot hide (matrix pipe 34 % busy, waves 47 % in s_waitcnt).  With one pattern per lane
+// every per-pattern quantity halves (chained result 40 VGPRs, operands 10, left result 10): the kernel fits 128 VGPRs = 4 waves
+// per SIMD with register chaining KEPT.  A workgroup is still one 128-pattern tile, now 8 waves (512 threads) sharing the staged
+// fragment sets; two workgroups per CU = the same 256 patterns in flight per CU, as 16 waves instead of 8.  The price: an A
+// fragment read from LDS feeds one MFMA instead of two (LDS reads = MFMA count: the LDS pipe is as busy as the matrix pipe).
+// Arithmetic per pattern is unchanged (the four blocks of v_mfma_f64_4x4x4_4b are independent 4x4x4 products): same bits.
+// RESULT (same box, rotated order, profiles/r03_ab_k_oplist16.txt): SLOWER -- 0.797 ms per C3 scoring launch against 0.676 ms of
+// k_oplist<11> (stored traversal 0.93 vs 0.77).  The kernel does not fit its 128 VGPRs (46 spills, in prologue and epilogue), the
+// fragment reads cannot be software-pipelined inside that budget (each k-step waits for its five ds_reads: 480 s_waitcnt per
+// 500 MFMAs), and twice the LDS reads per MFMA are exposed instead of hidden.  Kept as an A-B arm (PML_CHAIN_VARIANT=16), not used.
+// Lane (j = lane & 15, q = lane >> 4): B operand = CLV[state 4 kk + q][pattern j], D = out[state 4 st + q][pattern j].
+// ------------------------------------------------------------------------------------------
+struct Operand1 { double v[5]; };
+
+__device__ __forceinline__ void load_clv1(Operand1 &o, gcptr base, unsigned lane_off, size_t rowbytes, int c) {
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk)
+        o.v[kk] = __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS double *>(base + (size_t)(c * NS + kk * 4) * rowbytes + lane_off));
+}
+__device__ __forceinline__ void load_tip1(Operand1 &o, const unsigned char *__restrict__ T, unsigned code, int q) {
+    const unsigned char *t0 = T + code * NS + q;
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) o.v[kk] = (double)t0[kk * 4];
+}
+__device__ __forceinline__ void contract1(double (&acc)[5], const double *__restrict__ frag_c, const Operand1 &o) {
+    // no software pipelining of the fragment reads: the ten registers of a second fragment column push the kernel further over
+    // its 128-VGPR budget (58 spills instead of 46) and measured slower (0.827 vs 0.797 ms per C3 launch)
+#pragma unroll
+    for (int st = 0; st < 5; ++st) acc[st] = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) {
+        double a[5];
+#pragma unroll
+        for (int st = 0; st < 5; ++st) a[st] = frag_c[(st * 5 + kk) * 16];
+#pragma unroll
+        for (int st = 0; st < 5; ++st) acc[st] = mfma4(a[st], o.v[kk], acc[st]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <typename F>
+__device__ __forceinline__ void contract_stream1(const double *__restrict__ frag_c, const Operand1 &o, F &&consume) {
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        double a[5];
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk) a[kk] = frag_c[(st * 5 + kk) * 16];
+        double acc = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk) acc = mfma4(a[kk], o.v[kk], acc);
+        consume(st, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+__device__ __forceinline__ void load_cherry1(Operand1 &o, const OpSide &sd, unsigned ca, unsigned cb, int c, int q) {
+    const Rows5 a = load_rows(sd.t0, ca, c, q), b = load_rows(sd.t1, cb, c, q);
+    o.v[0] = a.a.x * b.a.x; o.v[1] = a.a.y * b.a.y; o.v[2] = a.b.x * b.b.x; o.v[3] = a.b.y * b.b.y; o.v[4] = a.c * b.c;
+}
+__device__ __forceinline__ void load_pitch1(Operand1 &o, const OpSide &sd, const double *__restrict__ f_inner,
+                                            unsigned ca, unsigned cb, unsigned cc, int c, int q) {
+    Operand1 w;
+    load_cherry1(w, sd, ca, cb, c, q);
+    double v[5];
+    contract1(v, f_inner + c * 25 * 16, w);
+    const Rows5 r = load_rows(sd.t2, cc, c, q);
+    o.v[0] = v[0] * r.a.x; o.v[1] = v[1] * r.a.y; o.v[2] = v[2] * r.b.x; o.v[3] = v[3] * r.b.y; o.v[4] = v[4] * r.c;
+}
+
+// one op on one chunk of 16 patterns of one wave (the twin of chunk_op<false, true, false>)
+__device__ __forceinline__ void chunk_op1(const NvOp &op, const double *__restrict__ sP, const unsigned char *__restrict__ sT,
+                                          int p, int lane, Operand1 (&X)[4], int &xsc) {
+    const int q = lane >> 4;
+    constexpr size_t rowbytes = (size_t)TILE_PAT * 8;
+    const size_t tabrow = (size_t)op.mpad * 8;
+    const unsigned lane_off = (unsigned)(p >> 7) * (unsigned)(CLV_ROWS * rowbytes) + (unsigned)((size_t)q * rowbytes) + (unsigned)(p & (TILE_PAT - 1)) * 8u;
+    const int lk = op.flags & 3, rk = (op.flags >> 2) & 3;
+    const bool nt_store = (op.flags & OPF_NT_STORE) != 0;
+    const int mode = op.mode;
+    const bool chL = (op.flags & OPF_CHAIN_L) != 0, chR = (op.flags & OPF_CHAIN_R) != 0;
+    const bool keep = (op.flags & OPF_NO_STORE) == 0;
+    gcptr Lp = (gcptr)op.l.p0, Rp = (gcptr)op.r.p0;
+    gptr O = (gptr)op.out;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)op.out, 0, 0x7FFFFFFF, 0x00020000);
+    const double *fL = sP + (q * 4 + (lane & 3));
+    const double *fR = fL + PFRAG;
+    double mx = 0.0, site = 0.0;
+    unsigned cl = 0, cl2 = 0, cl3 = 0, cr = 0, cr2 = 0, cr3 = 0;
+    const double *fLi = fL + 2 * PFRAG;
+    const double *fRi = (lk == SK_PITCH) ? op.r.f + (q * 4 + (lane & 3)) : fL + 2 * PFRAG;
+    if (lk != SK_CLV) cl = *reinterpret_cast<const GLOBAL_AS unsigned char *>(Lp + p);
+    if (lk >= SK_CHERRY) cl2 = *reinterpret_cast<const GLOBAL_AS unsigned char *>((gcptr)op.l.p1 + p);
+    if (lk == SK_PITCH) cl3 = *reinterpret_cast<const GLOBAL_AS unsigned char *>((gcptr)op.l.p2 + p);
+    if (rk != SK_CLV) cr = *reinterpret_cast<const GLOBAL_AS unsigned char *>(Rp + p);
+    if (rk >= SK_CHERRY) cr2 = *reinterpret_cast<const GLOBAL_AS unsigned char *>((gcptr)op.r.p1 + p);
+    if (rk == SK_PITCH) cr3 = *reinterpret_cast<const GLOBAL_AS unsigned char *>((gcptr)op.r.p2 + p);
+    // plain tip sides by look-up of the fragment set's column (same rule as chunk_op: the whole wave or not at all)
+    const bool lookL = mode < MODE_EVALUATE && lk == SK_TIP && !__any(cl >= 20u);
+    const bool lookR = mode < MODE_EVALUATE && rk == SK_TIP && !__any(cr >= 20u);
+    const double *tL = sP + (cl >> 2) * 16 + (cl & 3u) * 4 + q;
+    const double *tR = sP + PFRAG + (cr >> 2) * 16 + (cr & 3u) * 4 + q;
+    Operand1 curL, curR;
+    if (lk == SK_TIP && !lookL) load_tip1(curL, sT, cl, q);
+    else if (lk == SK_CLV && !chL) load_clv1(curL, Lp, lane_off, rowbytes, 0);
+    if (rk == SK_TIP && !lookR) load_tip1(curR, sT, cr, q);
+    else if (rk == SK_CLV && !chR) load_clv1(curR, Rp, lane_off, rowbytes, 0);
+#pragma unroll
+    for (int c = 0; c < NCAT; ++c) {
+        Operand1 Y;
+        if (chL) curL = X[c];
+        if (chR) curR = X[c];
+        if (lk == SK_CHERRY) load_cherry1(curL, op.l, cl, cl2, c, q);
+        else if (lk == SK_PITCH) load_pitch1(curL, op.l, fLi, cl, cl2, cl3, c, q);
+        if (rk == SK_CHERRY) load_cherry1(curR, op.r, cr, cr2, c, q);
+        else if (rk == SK_PITCH) load_pitch1(curR, op.r, fRi, cr, cr2, cr3, c, q);
+        if (mode >= MODE_EVALUATE) {
+            contract_stream1(fR + c * 25 * 16, curR, [&](int st, double y) { site += curL.v[st] * y; });
+            if (mode == MODE_EVALUATE_CAT) {
+                double a = site;
+                a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+                if (q == 0) *reinterpret_cast<GLOBAL_AS double *>(O + (size_t)c * tabrow + 8 * p) = a;
+                site = 0.0;
+            }
+        } else {
+            double aL[5];
+            if (lookL) {
+#pragma unroll
+                for (int st = 0; st < 5; ++st) aL[st] = tL[c * 400 + st * 80];
+            } else contract1(aL, fL + c * 25 * 16, curL);
+            auto emit = [&](int st, double y) {
+                const double o = aL[st] * y;
+                mx = fmax(mx, o);
+                Y.v[st] = o;
+                if (!keep) return;
+                typedef unsigned uvec2 __attribute__((ext_vector_type(2)));
+                const uvec2 bits = __builtin_bit_cast(uvec2, o);
+                const int soff = (c * NS + st * 4) * (int)rowbytes;
+                if (nt_store) __builtin_amdgcn_raw_buffer_store_b64(bits, orsrc, lane_off, soff, 2);
+                else __builtin_amdgcn_raw_buffer_store_b64(bits, orsrc, lane_off, soff, 0);
+            };
+            if (lookR) {
+#pragma unroll
+                for (int st = 0; st < 5; ++st) emit(st, tR[c * 400 + st * 80]);
+            } else contract_stream1(fR + c * 25 * 16, curR, emit);
+        }
+        if (mode == MODE_NEWVIEW) X[c] = Y;
+        if (c + 1 < NCAT) {
+            if (lk == SK_CLV && !chL) load_clv1(curL, Lp, lane_off, rowbytes, c + 1);
+            if (rk == SK_CLV && !chR) load_clv1(curR, Rp, lane_off, rowbytes, c + 1);
+        }
+    }
+    int sc = 0;
+    if (q == 0) {
+        if (lk == SK_CLV) { if (chL) sc += xsc; else sc += *reinterpret_cast<const GLOBAL_AS int *>((gcptr)op.l_scl + 4 * p); }
+        if (rk == SK_CLV) { if (chR) sc += xsc; else sc += *reinterpret_cast<const GLOBAL_AS int *>((gcptr)op.r_scl + 4 * p); }
+    }
+    if (mode == MODE_NEWVIEW) {
+        mx = fmax(mx, __shfl_xor(mx, 16)); mx = fmax(mx, __shfl_xor(mx, 32));
+        const bool n0 = mx < TWO_M256;
+        if (__any(n0)) {                     // rare: numerical rescue of underflowing patterns
+            const double f0 = n0 ? TWO_P256 : 1.0;
+#pragma unroll
+            for (int c = 0; c < NCAT; ++c)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) X[c].v[k] *= f0;
+            if (keep && n0) {
+#pragma unroll 1
+                for (int r = 0; r < NCAT * 5; ++r) {
+                    GLOBAL_AS double *ptr = reinterpret_cast<GLOBAL_AS double *>(O + (size_t)((r / 5) * NS + (r % 5) * 4) * rowbytes + lane_off);
+                    *ptr = *ptr * TWO_P256;
+                }
+            }
+        }
+        if (q == 0) { sc += n0 ? 1 : 0; if (keep) *reinterpret_cast<GLOBAL_AS int *>((gptr)op.out_scl + 4 * p) = sc; }
+        xsc = sc;
+    } else if (mode == MODE_SUMTABLE || mode == MODE_EVALUATE_CAT) {
+        if (q == 0) *reinterpret_cast<GLOBAL_AS int *>((gptr)op.out_scl + 4 * p) = sc;
+    } else {
+        site += __shfl_xor(site, 16); site += __shfl_xor(site, 32);
+        if (q == 0) *reinterpret_cast<GLOBAL_AS double *>(O + 8 * p) = log(site * 0.25) - sc * LOG_2_256;
+    }
+}
+
+constexpr int OPL16_THREADS = 512;                     // 8 waves x 16 patterns = one 128-pattern tile
+__global__ __launch_bounds__(OPL16_THREADS, 4) void k_oplist16(const NvOp *__restrict__ ops, const GeneRun *__restrict__ runs, int nruns,
+                                                               int blocks_per_gene) {
+    Operand1 X[4]; int xsc = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) X[c].v[k] = 0.0;
+    extern __shared__ double sP[];                      // 2 parities x [left | right | inner] fragment sets + the tip-indicator table
+    constexpr int PARITY_STRIDE = 3 * PFRAG;
+    unsigned char *sT = reinterpret_cast<unsigned char *>(sP + 6 * PFRAG);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int gi = xcd + 8 * (slot / blocks_per_gene), blk = slot % blocks_per_gene;
+    if (gi >= nruns) return;
+    const GeneRun run = runs[gi];
+    if (run.op_begin >= run.op_end) return;
+    const int mpad = ops[run.op_begin].mpad;
+    if (blk * TILE_PAT >= mpad) return;
+    const int p = blk * TILE_PAT + wave * 16 + (lane & 15);
+    const bool active = blk * TILE_PAT + wave * 16 < mpad;
+    auto stage = [&](const NvOp &op, double *dst) {     // the three fragment sets of one op by LDS-DMA: 37.5 x 1 KiB wave-instructions
+        for (int i = wave; i < 25; i += OPL16_THREADS / 64) {
+            const int e = i * 128 + lane * 2;
+            const double *g = (e < PFRAG) ? (op.pl ? op.pl : op.pr) + e : (op.pr ? op.pr : op.pl) + (e - PFRAG);
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)g, (__attribute__((address_space(3))) void *)(dst + i * 128), 16, 0, 0);
+        }
+        const int lk = op.flags & 3, rk = (op.flags >> 2) & 3;
+        const double *inner = (lk == SK_PITCH) ? op.l.f : (rk == SK_PITCH) ? op.r.f : nullptr;
+        if (inner == nullptr) return;
+        for (int i = wave; i < 13; i += OPL16_THREADS / 64) {
+            const int e = i * 128 + lane * 2;
+            if (e < PFRAG) __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(inner + e), (__attribute__((address_space(3))) void *)(dst + 2 * PFRAG + i * 128), 16, 0, 0);
+        }
+    };
+    for (int i = tid; i < TIPTAB; i += OPL16_THREADS) sT[i] = (unsigned char)((code_mask(i / NS) >> (i % NS)) & 1u);
+    stage(ops[run.op_begin], sP);
+    __syncthreads();
+    for (int oi = run.op_begin; oi < run.op_end; ++oi) {
+        const NvOp &op = ops[oi];
+        const int par = (oi - run.op_begin) & 1;
+        const double *buf = sP + par * PARITY_STRIDE;
+        if (oi + 1 < run.op_end) stage(ops[oi + 1], sP + (par ^ 1) * PARITY_STRIDE);
+        if (active) chunk_op1(op, buf, sT, p, lane, X, xsc);
+        __syncthreads();                                 // next fragments landed (vmcnt(0) + barrier), stores done
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // deterministic block reduction (fixed order: wave shuffle tree, then waves in index order)
 // ------------------------------------------------------------------------------------------
 template <int N, int WAVES>
@@ -1313,8 +1545,17 @@ static void launch_oplist_one(const NvOp *ops, const GeneRun *runs, int nruns, i
     if (any_pitch && (v == 2 || v == 3)) v = 1;          // pitchfork regions are not combined with double buffering
     if (chained) {                                       // the descriptors carry OPF_CHAIN_* flags: only these variants honour them
         static const int cv = std::getenv("PML_CHAIN_VARIANT") ? std::atoi(std::getenv("PML_CHAIN_VARIANT")) : 11;
-        v = cv == 9 ? 9 : 11;
+        v = cv == 9 ? 9 : (cv == 16 ? 16 : 11);
         if (ctl) v = 15;
+    }
+    if (v == 16) {                                       // one pattern per lane, 8 waves per tile (k_oplist16)
+        const size_t lds16 = (size_t)6 * PFRAG * sizeof(double) + 512;
+        static const hipError_t big16 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_oplist16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+        if (big16 == hipSuccess) {
+            hipLaunchKernelGGL(k_oplist16, grid, dim3(OPL16_THREADS), lds16, s, ops, runs, nruns, bpg_in);
+            return;
+        }
+        v = 11;
     }
     const bool dbuf = (v == 2 || v == 3);
     size_t lds = (size_t)((dbuf ? 4 : 2) + (any_pitch ? 1 : 0)) * PFRAG * sizeof(double) + 512;   // 38.9 KB with pitchforks: 4 per CU
