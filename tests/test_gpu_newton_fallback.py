@@ -45,6 +45,22 @@ def test_fused_newton_has_the_bits_of_the_unfused_form():
         assert fused[key] == unfused[key], key
 
 
+def test_search_groups_return_the_bits_of_the_undivided_call():
+    """api.cpp deals a search call of >= 64 small genes over groups (worker contexts, own streams and host threads): the genes'
+    results must not depend on the division -- undivided, the default (two groups) and three groups agree bit for bit"""
+    def run(groups):
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        if groups is not None:
+            env["PML_GROUPS"] = str(groups)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "groups_harness.py")], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return json.loads(p.stdout)
+    one, default, three = run(1), run(None), run(3)
+    for key in ("nni", "spr"):
+        assert default[key] == one[key] and three[key] == one[key], key
+    assert default["stats"]["newview"] > one["stats"]["newview"]        # the default really ran as more than one batch
+
+
 def test_two_contexts_search_concurrently_in_one_process(gpu_ctx):
     """two contexts (two streams) of ONE process searching at the same time: both succeed and each gene gets the bits of a
     lone search -- the layout whose spinning slices could starve each other under the old in-grid-order assumption"""
