@@ -484,9 +484,24 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
     constexpr bool PF_L = PREFETCH && !CHAIN;       // the chained variants prefetch the right side only (the chained child is the left one; registers)
     // (a plain tip side goes through the MFMA with its 0/1 indicator operand: the matrix pipe has slack and
     // table gathers for it measured slower)
-    gcptr Lp = (gcptr)op.l.p0, Rp = (gcptr)op.r.p0;
-    gptr O = (gptr)op.out;
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)op.out, 0, 0x7FFFFFFF, 0x00020000);   // raw buffer over the output CLV
+    // The descriptor fields the category loop needs are read ONCE, here, and pinned in SGPRs: a scalar load in the middle of a
+    // contraction costs far more than its own latency -- SMEM returns out of order, so the compiler has to wait for it with
+    // s_waitcnt lgkmcnt(0), which also drains every LDS fragment read that was requested ahead (78 such drains per operation
+    // before; the fragment reads showed up as 20 % of the launch in the ablations, profiles/r03_ablation_k_oplist.txt)
+#ifndef PML_PIN_DESC
+#define PML_PIN_DESC 1
+#endif
+    OpSide sdl = op.l, sdr = op.r;
+    const int *l_scl = op.l_scl, *r_scl = op.r_scl; int *out_scl = op.out_scl; double *outp = op.out;
+#if PML_PIN_DESC
+#define PML_PIN(x) asm volatile("" : "+s"(x))
+    PML_PIN(sdl.p0); PML_PIN(sdl.p1); PML_PIN(sdl.p2); PML_PIN(sdl.t0); PML_PIN(sdl.t1); PML_PIN(sdl.t2); PML_PIN(sdl.f);
+    PML_PIN(sdr.p0); PML_PIN(sdr.p1); PML_PIN(sdr.p2); PML_PIN(sdr.t0); PML_PIN(sdr.t1); PML_PIN(sdr.t2); PML_PIN(sdr.f);
+    PML_PIN(l_scl); PML_PIN(r_scl); PML_PIN(out_scl); PML_PIN(outp);
+#endif
+    gcptr Lp = (gcptr)sdl.p0, Rp = (gcptr)sdr.p0;
+    gptr O = (gptr)outp;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)outp, 0, 0x7FFFFFFF, 0x00020000);   // raw buffer over the output CLV
     // lane's A-fragment element: 4*k + i with k = q, i = lane&3
     const double *fL = sP + (q * 4 + (lane & 3));
     const double *fR = fL + PFRAG;
@@ -495,13 +510,13 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
     // inner fragments of a pitchfork side: ONE extra LDS region, owned by the left side if it is a
     // pitchfork, else by the right; if both are, the right side reads its set from global memory (rare)
     const double *fLi = fL + 2 * PFRAG;
-    const double *fRi = (lk == SK_PITCH) ? op.r.f + (q * 4 + (lane & 3)) : fL + 2 * PFRAG;
+    const double *fRi = (lk == SK_PITCH) ? sdr.f + (q * 4 + (lane & 3)) : fL + 2 * PFRAG;
     if (lk != SK_CLV) cl = *reinterpret_cast<const GLOBAL_AS unsigned short *>(Lp + p);
-    if (lk >= SK_CHERRY) cl2 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)op.l.p1 + p);
-    if (lk == SK_PITCH) cl3 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)op.l.p2 + p);
+    if (lk >= SK_CHERRY) cl2 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)sdl.p1 + p);
+    if (lk == SK_PITCH) cl3 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)sdl.p2 + p);
     if (rk != SK_CLV) cr = *reinterpret_cast<const GLOBAL_AS unsigned short *>(Rp + p);
-    if (rk >= SK_CHERRY) cr2 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)op.r.p1 + p);
-    if (rk == SK_PITCH) cr3 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)op.r.p2 + p);
+    if (rk >= SK_CHERRY) cr2 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)sdr.p1 + p);
+    if (rk == SK_PITCH) cr3 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)sdr.p2 + p);
 
     // A tip side with plain amino-acid codes needs no contraction: (P e_a)[s] = P[s][a] is an element of the fragment set
     // already in LDS (A-fragment order: P[4 st + i][4 kk + k] at (st*5 + kk)*16 + k*4 + i) -- 5 LDS reads per pattern and
@@ -528,10 +543,10 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
             if (PF_L && lk == SK_CLV && !chL) load_clv(nxtL, Lp, lane_off, rowbytes, c + 1);
             if (rk == SK_CLV && !chR) load_clv(nxtR, Rp, lane_off, rowbytes, c + 1);
         }
-        if (lk == SK_CHERRY) load_cherry(curL, op.l, cl, cl2, c, q);
-        else if (lk == SK_PITCH) load_pitch(curL, op.l, fLi, cl, cl2, cl3, c, q);
-        if (rk == SK_CHERRY) load_cherry(curR, op.r, cr, cr2, c, q);
-        else if (rk == SK_PITCH) load_pitch(curR, op.r, fRi, cr, cr2, cr3, c, q);
+        if (lk == SK_CHERRY) load_cherry(curL, sdl, cl, cl2, c, q);
+        else if (lk == SK_PITCH) load_pitch(curL, sdl, fLi, cl, cl2, cl3, c, q);
+        if (rk == SK_CHERRY) load_cherry(curR, sdr, cr, cr2, c, q);
+        else if (rk == SK_PITCH) load_pitch(curR, sdr, fRi, cr, cr2, cr3, c, q);
         if (mode >= MODE_EVALUATE) {
             contract_stream(fR + c * 25 * 16, curR, [&](int st, double y0, double y1) {
                 site0 += curL.v[st].x * y0; site1 += curL.v[st].y * y1;
@@ -583,8 +598,8 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
 
     ivec2 sc = {0, 0};
     if (q == 0) {
-        if (lk == SK_CLV) { if (chL) sc += xsc; else sc += *reinterpret_cast<const GLOBAL_AS ivec2 *>((gcptr)op.l_scl + 4 * p); }
-        if (rk == SK_CLV) { if (chR) sc += xsc; else sc += *reinterpret_cast<const GLOBAL_AS ivec2 *>((gcptr)op.r_scl + 4 * p); }
+        if (lk == SK_CLV) { if (chL) sc += xsc; else sc += *reinterpret_cast<const GLOBAL_AS ivec2 *>((gcptr)l_scl + 4 * p); }
+        if (rk == SK_CLV) { if (chR) sc += xsc; else sc += *reinterpret_cast<const GLOBAL_AS ivec2 *>((gcptr)r_scl + 4 * p); }
     }
     if (mode == MODE_NEWVIEW) {
         mx0 = fmax(mx0, __shfl_xor(mx0, 16)); mx0 = fmax(mx0, __shfl_xor(mx0, 32));
@@ -609,11 +624,11 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
                 }
             }
         }
-        if (q == 0) { sc.x += n0 ? 1 : 0; sc.y += n1 ? 1 : 0; if (keep) *reinterpret_cast<GLOBAL_AS ivec2 *>((gptr)op.out_scl + 4 * p) = sc; }
+        if (q == 0) { sc.x += n0 ? 1 : 0; sc.y += n1 ? 1 : 0; if (keep) *reinterpret_cast<GLOBAL_AS ivec2 *>((gptr)out_scl + 4 * p) = sc; }
         if (CHAIN) xsc = sc;
     } else if (mode == MODE_SUMTABLE || mode == MODE_EVALUATE_CAT) {
         if (fusedN) xsc = sc;
-        else if (q == 0) *reinterpret_cast<GLOBAL_AS ivec2 *>((gptr)op.out_scl + 4 * p) = sc;
+        else if (q == 0) *reinterpret_cast<GLOBAL_AS ivec2 *>((gptr)out_scl + 4 * p) = sc;
     } else {
         site0 += __shfl_xor(site0, 16); site0 += __shfl_xor(site0, 32);
         site1 += __shfl_xor(site1, 16); site1 += __shfl_xor(site1, 32);

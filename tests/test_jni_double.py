@@ -1,0 +1,102 @@
+"""bindings/jni/peprml_jni.c -- the JNI glue a PEPR maintainer ships -- compiled and DRIVEN without a JVM:
+tests/jni_double/jni.h is a test double of the JNI header (the types and the twelve JNIEnv entries the glue uses, signatures as
+the JNI specification gives them), jni_double.c implements those entries over plain C objects and passes the glue the String[] /
+char[][] arguments FastTreeRunner / RAxMLRunner would (SequenceAlignment.java:61).  Not a JDK, not a JVM: what this proves is that
+the marshalling code compiles, pins and releases in pairs, maps failure to null (FastTreeRunner.java:125-131) and returns what the
+C ABI returns."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from pepr_amd import engine, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "tests", "jni_double", "libjni_double.so")
+
+
+def _lib():
+    if not os.path.exists(SO):
+        import __graft_entry__ as g
+        g.build_jni_double()
+    L = C.CDLL(SO)
+    cpp = C.POINTER(C.c_char_p)
+    L.jd_search.restype = C.c_void_p; L.jd_search.argtypes = [C.c_int, cpp, cpp, C.c_char_p, C.c_int, C.c_int]
+    L.jd_optimize.restype = C.c_void_p; L.jd_optimize.argtypes = [C.c_int, cpp, cpp, C.c_char_p]
+    L.jd_parsimony.restype = C.c_void_p; L.jd_parsimony.argtypes = [C.c_int, cpp, cpp, C.c_int]
+    L.jd_site_lnl.argtypes = [C.c_int, cpp, cpp, C.c_char_p, C.POINTER(C.c_double), C.c_int]
+    L.jd_jackknife.argtypes = [C.c_int, C.POINTER(C.c_int), cpp, cpp, C.c_int, C.c_longlong, C.POINTER(C.c_void_p)]
+    L.jd_pin_counts.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    L.jd_free.argtypes = [C.c_void_p]
+    return L
+
+
+def _arr(strings):
+    return (C.c_char_p * len(strings))(*[s.encode() for s in strings])
+
+
+def _take(L, p):
+    if not p:
+        return None
+    s = C.string_at(p).decode()
+    L.jd_free(p)
+    return s
+
+
+def test_jni_glue_compiles_and_exports_the_entry_points():
+    L = _lib()
+    for name in ("search", "optimize", "siteLnL", "jackknife", "parsimony", "bootstrap", "shSupport"):
+        assert hasattr(L, "Java_edu_vt_vbi_ci_pepr_tree_NativeTreeEngine_" + name), name
+    # the Java side declares the same natives
+    java = open(os.path.join(ROOT, "bindings", "jni", "NativeTreeEngine.java")).read()
+    for name in ("search", "optimize", "siteLnL", "jackknife", "parsimony", "bootstrap", "shSupport"):
+        assert "native" in java and name + "(" in java, name
+
+
+def test_jni_failure_maps_to_null_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = _lib()
+    names, rows, nw = synth.simulate_alignment(5, 40, 1)
+    assert L.jd_search(5, _arr(names), _arr(rows), None, 1, 0) is None       # pml_create fails -> null tree string, no crash
+
+
+@pytest.mark.gpu
+def test_jni_glue_returns_what_the_c_abi_returns(gpu_ctx):
+    L = _lib()
+    names, rows, nw = synth.simulate_alignment(11, 320, 4711, missing_frac=0.1)
+    gene = (names, rows)
+    got = _take(L, L.jd_search(len(names), _arr(names), _arr(rows), None, 1, 5))
+    ref = gpu_ctx.search_one(gene, None, nni=True, spr_radius=5, epsilon=1e-3)
+    assert got == ref["newick"]
+    # a start tree travels as a Java String
+    got2 = _take(L, L.jd_search(len(names), _arr(names), _arr(rows), nw.encode(), 1, 0))
+    assert got2 == gpu_ctx.search_one(gene, nw, nni=True, spr_radius=0, epsilon=1e-3)["newick"]
+    opt = _take(L, L.jd_optimize(len(names), _arr(names), _arr(rows), nw.encode()))
+    assert opt == gpu_ctx.optimize_one(gene, nw)["newick"]
+    out = (C.c_double * 400)()
+    n = L.jd_site_lnl(len(names), _arr(names), _arr(rows), nw.encode(), out, 400)
+    o = gpu_ctx.optimize_one(gene, nw)
+    ref_sites = gpu_ctx.score([gene], [o["newick"]], alpha=o["alpha"], site_lnl=True)[0]["site_lnl"]
+    assert n == 320 and np.array_equal(np.array(out[:n]), ref_sites)
+    assert _take(L, L.jd_parsimony(len(names), _arr(names), _arr(rows), 7)) == gpu_ctx.parsimony([gene], seed=7)[0]["newick"]
+    # a ragged char[][] (rows of different lengths) is a failed build -> null, as the runners expect
+    bad = list(rows); bad[3] = bad[3][:-1]
+    assert L.jd_search(len(names), _arr(names), _arr(bad), None, 1, 0) is None
+    # jackknife: String[][] + char[][][] in, String[reps + 1] out (supported tree first)
+    genes = []
+    for g in range(5):
+        n_, r_, _ = synth.simulate_alignment(8, 100 + 10 * g, 4800 + g, names=["t%d" % i for i in range(8)])
+        genes.append((n_, r_))
+    flat_n = sum((g[0] for g in genes), []); flat_r = sum((g[1] for g in genes), [])
+    ntax = (C.c_int * 5)(*[len(g[0]) for g in genes])
+    res = (C.c_void_p * 5)()
+    k = L.jd_jackknife(5, ntax, _arr(flat_n), _arr(flat_r), 4, 9, res)
+    ref = gpu_ctx.jackknife(genes, reps=4, seed=9, spr_radius_full=5)
+    got = [_take(L, res[i]) for i in range(k)]
+    assert k == 5 and got[0] == ref["newick"] and got[1:] == ref["support_trees"]
+    pins, unpins = C.c_long(), C.c_long()
+    L.jd_pin_counts(C.byref(pins), C.byref(unpins))
+    assert pins.value > 0 and pins.value == unpins.value            # everything pinned was released
