@@ -342,6 +342,9 @@ typedef __attribute__((address_space(1))) char *gptr;           // from a descri
 // rotated order: C3 scoring launch 0.93-1.00 ms plain, 0.92-0.98 nt loads, 0.85-0.86 nt loads + nt stores; C4 shard 10.1 /
 // 9.3 / 9.9 ms -- profiles/r02_ab_nontemporal.txt).
 __device__ __forceinline__ void load_clv(Operand &o, gcptr base, unsigned lane_off, size_t rowbytes, int c) {
+#ifdef ABL_NO_CLV
+    { for (int kk = 0; kk < 5; ++kk) o.v[kk] = (dvec2){0.05 + 1e-12 * lane_off, 0.05}; return; }
+#endif
 #pragma unroll
     for (int kk = 0; kk < 5; ++kk)
         o.v[kk] = __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS dvec2 *>(base + (size_t)(c * NS + kk * 4) * rowbytes + lane_off));
@@ -364,18 +367,23 @@ __device__ __forceinline__ void contract(double (&acc)[5][2], const double *__re
     // launch 0.677 ms; fragment reads made free 0.545, tip-table rows free 0.553, CLV loads free 0.645, no per-op barrier 0.687)
     // say the LDS reads cost 20 % -- but two steps ahead (10 more VGPRs, 3 spills) measures 0.677 vs 0.673: it is not the
     // latency of one read that is exposed
+#ifdef ABL_NO_LDS
+#define FRAG_RD(x) (0.05)
+#else
+#define FRAG_RD(x) (x)
+#endif
     double a[3][5];
 #pragma unroll
-    for (int st = 0; st < 5; ++st) { acc[st][0] = 0.0; acc[st][1] = 0.0; a[0][st] = frag_c[(st * 5) * 16]; }
+    for (int st = 0; st < 5; ++st) { acc[st][0] = 0.0; acc[st][1] = 0.0; a[0][st] = FRAG_RD(frag_c[(st * 5) * 16]); }
     if (PML_FRAG_AHEAD >= 2) {
 #pragma unroll
-        for (int st = 0; st < 5; ++st) a[1][st] = frag_c[(st * 5 + 1) * 16];
+        for (int st = 0; st < 5; ++st) a[1][st] = FRAG_RD(frag_c[(st * 5 + 1) * 16]);
     }
 #pragma unroll
     for (int kk = 0; kk < 5; ++kk) {
         if (kk + PML_FRAG_AHEAD < 5) {
 #pragma unroll
-            for (int st = 0; st < 5; ++st) a[(kk + PML_FRAG_AHEAD) % 3][st] = frag_c[(st * 5 + kk + PML_FRAG_AHEAD) * 16];
+            for (int st = 0; st < 5; ++st) a[(kk + PML_FRAG_AHEAD) % 3][st] = FRAG_RD(frag_c[(st * 5 + kk + PML_FRAG_AHEAD) * 16]);
         }
 #pragma unroll
         for (int st = 0; st < 5; ++st) {
@@ -393,16 +401,16 @@ template <typename F>
 __device__ __forceinline__ void contract_stream(const double *__restrict__ frag_c, const Operand &o, F &&consume) {
     double a[3][5];
 #pragma unroll
-    for (int kk = 0; kk < 5; ++kk) a[0][kk] = frag_c[kk * 16];
+    for (int kk = 0; kk < 5; ++kk) a[0][kk] = FRAG_RD(frag_c[kk * 16]);
     if (PML_FRAG_AHEAD >= 2) {
 #pragma unroll
-        for (int kk = 0; kk < 5; ++kk) a[1][kk] = frag_c[(5 + kk) * 16];
+        for (int kk = 0; kk < 5; ++kk) a[1][kk] = FRAG_RD(frag_c[(5 + kk) * 16]);
     }
 #pragma unroll
     for (int st = 0; st < 5; ++st) {
         if (st + PML_FRAG_AHEAD < 5) {
 #pragma unroll
-            for (int kk = 0; kk < 5; ++kk) a[(st + PML_FRAG_AHEAD) % 3][kk] = frag_c[((st + PML_FRAG_AHEAD) * 5 + kk) * 16];
+            for (int kk = 0; kk < 5; ++kk) a[(st + PML_FRAG_AHEAD) % 3][kk] = FRAG_RD(frag_c[((st + PML_FRAG_AHEAD) * 5 + kk) * 16]);
         }
         double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
@@ -418,7 +426,12 @@ __device__ __forceinline__ void contract_stream(const double *__restrict__ frag_
 // cherry operand: product of the two tips' table rows (tables live in global memory, L2-resident:
 // every workgroup of the gene reads the same 2 x 17.7 KB); a lane's five rows are 40 contiguous bytes
 struct Rows5 { dvec2 a, b; double c; };
+// (ABL_* macros: timing-only ablation builds of tools/ab_ablation.sh -- a source of stalls is replaced by constants to see what it
+// costs; results are NOT likelihoods.  Never defined in the product build.)
 __device__ __forceinline__ Rows5 load_rows(const double *tab, unsigned code, int c, int q) {
+#ifdef ABL_NO_ROWS
+    { Rows5 r1; r1.a = (dvec2){0.9, 0.9}; r1.b = (dvec2){0.9, 0.9}; r1.c = 0.9 + 1e-9 * code; return r1; }
+#endif
     gcptr p = (gcptr)tab + (size_t)((c * NCODES + code) * 4 + q) * (TIPTAB_KK * 8);
     Rows5 r;
     r.a = *reinterpret_cast<const GLOBAL_AS dvec2 *>(p);
@@ -861,7 +874,9 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : (VARIANT >= 8) ? PML_CHAI
                 if (tid == 0 && blk == 0) { r.out[0] = r.t0; r.out[1] = __builtin_nan(""); r.out[2] = 0.0; r.out[3] = 0.0; }
             } else newton_fused(op, const_cast<double *>(buf), X, xsc, active, blk, ctl, timeout_ticks);
         }
+#ifndef ABL_NO_BARRIER
         if (DBUF) __syncthreads();           // next fragments landed (vmcnt(0) + barrier), stores done
+#endif
     }
     leave();
 }

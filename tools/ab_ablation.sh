@@ -1,5 +1,8 @@
 #!/bin/bash
-# timing-only ablations of k_oplist<11> (results are NOT valid likelihoods): which source of stalls is worth how much
+# timing-only ablations of k_oplist<11> (results are NOT valid likelihoods): which source of stalls is worth how much.
+# Build the arms first, in the container (hipcc cross-compiles; the .so files travel with gpurun):
+#   for a in NO_ROWS NO_CLV NO_LDS NO_BARRIER; do (cd pepr_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DABL_$a -x hip \
+#       kernels.hip parsimony.hip engine.cpp host.cpp api.cpp search.cpp jackknife.cpp -shared -pthread -o ../../build_ab/libpeprml_$a.so); done
 cat > /tmp/abl.py <<'PY'
 import os, sys, time
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
