@@ -1,7 +1,7 @@
 #!/bin/bash
 # same-box A/B of the number of groups a search call is dealt over (PML_GROUPS): tools/ab_groups.sh OUT
 O=gpurun_out/$1; mkdir -p $O
-for g in 1 2 3 0 0; do
+for g in 2 4 3 4 2 3; do
   PML_GROUPS=$g BENCH_NO_C4=1 timeout -k 10 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/g$g.json 2> $O/g$g.err || echo "groups $g failed"
   python - <<PY
 import json
