@@ -296,7 +296,7 @@ static int search_groups(int n, const pml_alignment *alns) {
     const int tiles = (maxcols + 127) / 128;
     int g = env > 0 ? std::min(env, 8) : 2;                // two by default: 3 measured 179-215 from run to run, 2 stays at 195-200
     if (env <= 0) { while (g > 1 && n / g < 32) --g; }
-    while (g > 1 && tiles * g > 32) --g;
+    if (!std::getenv("PML_GROUPS_FORCE")) { while (g > 1 && tiles * g > 32) --g; }       // (experiment switch: lifts the tile rule)
     return std::max(g, 1);
 }
 
