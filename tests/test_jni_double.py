@@ -100,3 +100,26 @@ def test_jni_glue_returns_what_the_c_abi_returns(gpu_ctx):
     pins, unpins = C.c_long(), C.c_long()
     L.jd_pin_counts(C.byref(pins), C.byref(unpins))
     assert pins.value > 0 and pins.value == unpins.value            # everything pinned was released
+
+
+@pytest.mark.gpu
+def test_aquificales_tree_building_step_through_the_jni_glue(gpu_ctx):
+    """BASELINE configs[1] as far as it can be run here: the Aquificales stand-in genes (tests/golden/standin_Aquificales.json)
+    handed to NativeTreeEngine.jackknife the way buildConcatenatedTreeWithGeneWiseJackKnifeSupport would
+    (PhylogenomicPipeline2.java:994-1126: String[][] taxa + char[][][] rows per gene) -- through the JNI glue and the JNI test
+    double, no JVM -- returns the supported tree and support trees of the ctypes path bit for bit"""
+    import json
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "standin_Aquificales.json")))
+    genes = [(g["names"], g["rows"]) for g in d["genes"]]
+    L = _lib()
+    reps = 6
+    flat_n = sum((g[0] for g in genes), []); flat_r = sum((g[1] for g in genes), [])
+    ntax = (C.c_int * len(genes))(*[len(g[0]) for g in genes])
+    res = (C.c_void_p * (reps + 1))()
+    k = L.jd_jackknife(len(genes), ntax, _arr(flat_n), _arr(flat_r), reps, 11, res)
+    got = [_take(L, res[i]) for i in range(max(k, 0))]
+    ref = gpu_ctx.jackknife(genes, reps=reps, seed=11, spr_radius_full=5)
+    assert k == reps + 1 and got[0] == ref["newick"] and got[1:] == ref["support_trees"]
+    import re
+    sup = [int(x) for x in re.findall(r"\)(\d+):", got[0])]
+    assert len(sup) == len(d["taxa"]) - 3 and max(sup) == reps
