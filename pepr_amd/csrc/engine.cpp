@@ -754,11 +754,11 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     // iterated inside k_oplist<11> on the register-resident sumtable; PML_NO_FUSE=1 is the A-B arm, safe mode (after an exchange
     // gave up) runs unfused through the no-exchange k_newton form
     static const bool fuse_env = std::getenv("PML_NO_FUSE") == nullptr && !(std::getenv("PML_CHAIN") && std::atoi(std::getenv("PML_CHAIN")) == 0);   // PML_CHAIN=0: the plain kernel only
-    // genes of more than 32 tiles are fused only when the whole launch is resident at once (kernels.hip launch_oplist): cut into
-    // several resident launches a step pays the Newton latency once per launch -- measured on a C4 shard (63 genes x 39 tiles,
-    // five launches per step) 14.8 s against 13.4 s unfused, while 16 such genes (two launches) gain 12 %
+    // (genes of more than 32 tiles: kernels.hip launch_oplist -- one launch with one ticket partition over the device by default;
+    // with PML_FUSE_BIG=0 only when the whole launch is resident at once: cut into several resident launches a step pays the
+    // Newton latency once per launch, measured slower than un-fused on a C4 shard)
     bool fuse_ok = fuse_env && !newton_safe_mode();
-    if (fuse_ok && nnewton) {
+    if (fuse_ok && nnewton && !fuse_big_genes()) {
         int mm = 0; size_t nr = 0;
         std::vector<char> seen(genes.size(), 0);
         for (auto &o : ops) if (!seen[o.gene]) { seen[o.gene] = 1; ++nr; mm = std::max(mm, genes[o.gene].aln.mpad); }

@@ -185,6 +185,9 @@ void launch_eigfrags_n(const ModelDev *models, double *frags2, int n, hipStream_
 void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, bool any_pitch, bool chained, hipStream_t s, NewtonCtl *ctl = nullptr);
 // workgroups of the fused-Newton op-list kernel the idle device holds at once (2 per CU)
 int fused_oplist_capacity();
+// genes of more than 32 tiles are fused in ONE launch with one ticket partition over the device (default; PML_FUSE_BIG=0: only
+// when the whole launch is resident at once)
+bool fuse_big_genes();
 void launch_reduce(const ReduceReq *reqs, int n, hipStream_t s);
 // tickets: request index per ticket, register-form tickets [0, nreg) then streaming-form [nreg, nreg + nstream)
 void launch_newton(const ModelDev *model, const NewtonReq *reqs, const int *tickets, int nreg, int nstream, NewtonCtl *ctl, hipStream_t s);

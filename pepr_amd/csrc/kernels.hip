@@ -1547,24 +1547,33 @@ static int oplist_variant() {
 static long long newton_timeout_ticks();
 static void launch_oplist_one(const NvOp *ops, const GeneRun *runs, int nruns, int bpg, bool one_part, bool any_pitch, bool chained, hipStream_t s, NewtonCtl *ctl);
 int fused_oplist_capacity();
+bool fuse_big_genes();
 void launch_oplist(const NvOp *ops, const GeneRun *runs, int nruns, int max_mpad, bool any_pitch, bool chained, hipStream_t s, NewtonCtl *ctl) {
     if (nruns <= 0) return;
     const int bpg = (max_mpad + PAT_PER_WG - 1) / PAT_PER_WG;
     if (!ctl) { launch_oplist_one(ops, runs, nruns, bpg, false, any_pitch, chained, s, nullptr); return; }
-    // Launches with fused Newton tails: the workgroups of a gene WAIT for each other.  Slots are claimed by ticket per XCD
-    // (workgroup b runs on XCD b % 8: tools/ubench_xcc.hip), so on every XCD all genes but the newest are fully staffed, and the
-    // newest needs room for its missing tiles on THAT XCD.  An XCD holds 64 of these workgroups at best (32 CUs x 2: 77 KB of
-    // LDS each, and only when the allocator packs a CU's two without a hole) but always 32 (one per CU).  Measured with
-    // tools/ubench_ticket.hip: gangs of up to 32 never stall however oversubscribed the launch; gangs of 35 / 40 stall now and
-    // then, gangs of 63 always -- and 16 genes of 200 x 5000 (35 tiles each) did in the engine.  Hence:
-    //   bpg <= 32: ONE launch, however many genes (C3: 128 genes x 8 tiles on 512 slots);
-    //   bpg  > 32: the gene list is cut into launches that are resident as a whole on the idle device (<= cap / bpg genes, one
-    //              ticket partition), so that no workgroup ever waits for one that has not been dispatched.
+    // Launches with fused Newton tails: the workgroups of a gene WAIT for each other, and slots are claimed by ticket (whoever
+    // holds a ticket is running, and so is every holder of a lower ticket of its partition: all genes but the newest are fully
+    // staffed).  What is left to the hardware is to place the newest gene's missing tiles when slots come free -- and that it
+    // does NOT do reliably when they are bound to one XCD (workgroup b runs on XCD b % 8: tools/ubench_xcc.hip): with one ticket
+    // partition per XCD, tools/ubench_ticket.hip stalls for good with gangs of 63 (always), 35 and 40 (now and then) although
+    // slots are free, never with gangs <= 32 (an XCD always has room for 32 of these workgroups, one per CU), and 16 genes of
+    // 200 x 5000 (35 tiles) did the same in the engine.  With ONE partition over the whole device -- a gang's members on any
+    // XCD -- no configuration ever stalled (72 configurations, gangs 33..64, up to 5x oversubscribed:
+    // profiles/r03_ubench_ticket_dispatch.txt; the engine: C4 shard, 2457 workgroups on 512 slots).  Hence:
+    //   bpg <= 32: one ticket partition per XCD, which keeps a gene's tiles -- and its fragment sets -- on one L2 (C3);
+    //   bpg  > 32: one partition over the device (a C4 shard searches in 10.65 s against 11.0 s un-fused).
+    // PML_FUSE_BIG=0 restores the conservative rule for the second case (fused only when the whole launch is resident at once).
     if (bpg <= 32) { launch_oplist_one(ops, runs, nruns, bpg, false, any_pitch, true, s, ctl); return; }
+    if (fuse_big_genes()) { launch_oplist_one(ops, runs, nruns, bpg, true, any_pitch, true, s, ctl); return; }
     const int cap = fused_oplist_capacity();
     const int genes_per_launch = std::max(1, cap / bpg);
     for (int off = 0; off < nruns; off += genes_per_launch)
         launch_oplist_one(ops, runs + off, std::min(genes_per_launch, nruns - off), bpg, true, any_pitch, true, s, ctl);
+}
+bool fuse_big_genes() {
+    static const bool on = !(std::getenv("PML_FUSE_BIG") && std::atoi(std::getenv("PML_FUSE_BIG")) == 0);
+    return on;
 }
 int fused_oplist_capacity() {
     static const int cap = [] {
