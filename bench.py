@@ -434,27 +434,39 @@ def main():
         sb.close()
         warm1, _, _, sb = infer()              # second call: the context keeps its arena, clocks are up
         sb.close()
-        sctx.kernel_stats(reset=True)
-        sdt, tc, slnl, sb = infer()            # third call = the reported steady state
-        sst = sctx.kernel_stats()
+        # calls three to five = the steady state; the MEDIAN is reported (the groups a search call is dealt over share the device
+        # through hardware queues whose interleaving differs from call to call: 188-212 gene-trees/s on C3), all three are listed
+        steady = []
+        for rep in range(3):
+            sctx.kernel_stats(reset=True)
+            sdt_i, tc, slnl, sb = infer()
+            sst_i = sctx.kernel_stats()
+            steady.append((sdt_i, sst_i))
+            if rep < 2:
+                sb.close()
+        order = sorted(range(3), key=lambda i: steady[i][0])
+        sdt, sst = steady[order[1]]
         rf = [engine.rf_distance(genes[i][2], sb.newick(i)) for i in range(len(genes))]
         sb.close()
         # the RAxML-path search (`raxmlHPC -f d`): parsimony start trees + NNI + lazy SPR radius 5, one one-shot call
         if ntax <= 64 and not os.environ.get("BENCH_NO_SPR"):
-            sync_all()
-            t0 = time.perf_counter()
-            sout = sctx.search(G, None, nni=True, spr_radius=5, epsilon=1e-3, seed=12345)
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            tspr, = rank_max(time.perf_counter() - t0)
-            spr = {"gene_trees_per_sec": total / tspr, "seconds": tspr,
+            tsprs = []
+            for rep in range(2):             # first call: the parsimony kernels' first use; the second is reported, both are listed
+                sync_all()
+                t0 = time.perf_counter()
+                sout = sctx.search(G, None, nni=True, spr_radius=5, epsilon=1e-3, seed=12345)
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                tsprs.append(rank_max(time.perf_counter() - t0)[0])
+            tspr = tsprs[1]
+            spr = {"gene_trees_per_sec": total / tspr, "seconds": tspr, "seconds_of_both_calls": tsprs,
                    "algorithm": "randomised stepwise-addition parsimony start + model optimisation + NNI + lazy SPR (radius 5), eps 1e-3",
                    "rf_to_generating_tree_mean_rank0": float(np.mean([engine.rf_distance(genes[i][2], sout[i]["newick"]) for i in range(len(genes))]))}
         nfb = sctx.newton_fallbacks()
         sctx.close()
-        sdt, cold = rank_max(sdt, cold)
-        search = {"gene_trees_per_sec": total / sdt, "seconds": sdt, "setup_seconds_rank0": tc,
+        sdt, cold = rank_max(sdt, cold)              # (N > 1: the slowest rank's median call)
+        search = {"gene_trees_per_sec": total / sdt, "seconds": sdt, "seconds_of_the_three_steady_calls_rank0": [x[0] for x in steady], "setup_seconds_rank0": tc,
                   "cold_first_call_seconds": cold, "cold_gene_trees_per_sec": total / cold, "second_call_seconds_rank0": warm1, "genes": total,
                   "algorithm": "NJ start + WAG+G4 model optimisation + NNI hill climbing (eps 1e-3); timed from host char rows to Newick",
                   "rf_to_generating_tree_mean_rank0": float(np.mean(rf)), "finite": bool(np.all(np.isfinite(slnl))),
