@@ -292,7 +292,14 @@ void Batch::destroy() {
     if (d_stage) hipFree(d_stage);
     if (d_frags) hipFree(d_frags);
     if (d_nsync) hipFree(d_nsync);
-    if (d_nctl) { hipFree(d_nctl); d_nctl = nullptr; }
+    if (d_nctl) {
+        if (std::getenv("PML_TRACE")) {
+            NewtonCtl h[2];
+            if (hipMemcpy(h, d_nctl, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[0].n_requests)
+                fprintf(stderr, "[pml] branch Newton: %llu requests, %.2f evaluations each\n", h[0].n_requests, (double)h[0].n_evals / (double)h[0].n_requests);
+        }
+        hipFree(d_nctl); d_nctl = nullptr;
+    }
     if (d_gmodel) { hipFree(d_gmodel); d_gmodel = nullptr; }
     if (d_geig) { hipFree(d_geig); d_geig = nullptr; }
     if (ev_stagger) { hipEventDestroy(ev_stagger); ev_stagger = nullptr; }

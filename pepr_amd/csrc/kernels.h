@@ -136,7 +136,8 @@ __host__ __device__ constexpr bool newton_reg_form(int mpad) { return newton_sli
 // oticket / odone: k_oplist launches with fused Newton tails claim (gene, tile) by ticket as well, one counter per XCD partition
 // dbg: what the first slice that gave up saw (diagnostic, printed under PML_TRACE): {1, slice, S, evaluation, mask of slices
 // whose granules had arrived (low / high 32), tag wanted, 0}
-struct NewtonCtl { int ticket[2]; int done[2]; int abort; int odone; int pad[2]; int oticket[8]; int dbg[8]; };
+struct NewtonCtl { int ticket[2]; int done[2]; int abort; int odone; int pad[2]; int oticket[8]; int dbg[8];
+                   unsigned long long n_requests, n_evals; };     // diagnostic totals (PML_TRACE): Newton requests served, evaluations made
 constexpr int NEWTON_SYNC_DOUBLES = 2 * NEWTON_MAX_SPLIT * 6;   // two parities x slices x six 8-byte {tag, half a double} granules (three partial sums)
 
 // MODE_EVALUATE_CAT: like MODE_EVALUATE but the four categories are NOT averaged: out[c][p] = sum_s L_c[s] (pi P_c . R_c)[s]

@@ -762,6 +762,7 @@ __device__ __forceinline__ void newton_fused(const NvOp &op, double *scratch, co
     double t, L, d1, d2;
     const bool ok = newton_drive(r.t0, r.max_iter, r.tol, eval_at, t, L, d1, d2);
     if (tid == 64 && blk == 0) {           // wave 1, lane 0 of the gene's first tile
+        atomicAdd(&ctl->n_requests, 1ull); atomicAdd(&ctl->n_evals, (unsigned long long)nevals);
         if (!ok) { t = r.t0; L = __builtin_nan(""); }      // exchange gave up: the host re-issues the step unfused (no-exchange form)
         r.out[0] = t; r.out[1] = L; r.out[2] = d1; r.out[3] = d2;
         if (r.t_dev0) { *r.t_dev0 = t; *r.t_dev1 = t; }
@@ -1336,6 +1337,7 @@ __device__ __forceinline__ void newton_body(const NewtonReq &r, NewtonShared &sh
     double t, L, d1, d2;
     const bool ok = newton_drive(r.t0, r.max_iter, r.tol, eval_at, t, L, d1, d2);
     if (ROLE == 2 && lane == 0 && wg == 0) {
+        atomicAdd(&ctl->n_requests, 1ull); atomicAdd(&ctl->n_evals, (unsigned long long)nevals);
         if (!ok) { t = r.t0; L = __builtin_nan(""); }      // exchange gave up: reported, the host re-issues the request (SEQ form)
         r.out[0] = t; r.out[1] = L; r.out[2] = d1; r.out[3] = d2;
         if (r.t_dev0) { *r.t_dev0 = t; *r.t_dev1 = t; }
