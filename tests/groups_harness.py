@@ -16,6 +16,7 @@ def main():
     s = ctx.search(G, None, nni=True, spr_radius=5, seed=11)
     out["spr"] = [[float(x["lnl"]).hex(), float(x["alpha"]).hex(), x["newick"]] for x in s]
     out["stats"] = {k: v["launches"] for k, v in ctx.kernel_stats().items()}
+    out["fallbacks"] = ctx.newton_fallbacks()
     ctx.close()
     json.dump(out, sys.stdout)
 

@@ -59,6 +59,14 @@ def test_search_groups_return_the_bits_of_the_undivided_call():
     for key in ("nni", "spr"):
         assert default[key] == one[key] and three[key] == one[key], key
     assert default["stats"]["newview"] > one["stats"]["newview"]        # the default really ran as more than one batch
+    # and with every exchange forced to give up inside the groups (each worker context falls back on its own): the same bits
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), PML_NEWTON_TIMEOUT_US="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "groups_harness.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    forced = json.loads(p.stdout)
+    for key in ("nni", "spr"):
+        assert forced[key] == one[key], key
+    assert forced["fallbacks"]["giveups"] > 0
 
 
 def test_two_contexts_search_concurrently_in_one_process(gpu_ctx):

@@ -54,6 +54,23 @@ def test_wagf_batch_of_genes_each_with_its_own_frequencies(gpu_ctx, oracle_lib):
         assert lone["lnl"] == opt[i]["lnl"] and lone["newick"] == opt[i]["newick"]
 
 
+def test_wagf_counts_ambiguity_codes_like_the_oracle(gpu_ctx, oracle_lib):
+    """an alignment full of B / Z / X / - / ? (they enter the frequency count proportionally) and with amino acids that never
+    occur (floored at 0.001): the device model is built from the same frequencies as the oracle's"""
+    po = oracle_lib
+    rng = np.random.default_rng(3)
+    names = ["t%d" % i for i in range(9)]
+    letters = list("ARNDCQEGHILK") + list("BZX-?") * 2          # M F P S T W Y V never occur
+    rows = ["".join(rng.choice(letters, 260)) for _ in names]
+    _, _, nw = synth.simulate_alignment(9, 10, 4, names=names)
+    a, e = _oracle(po, names, rows, 0.9)
+    f = po.empirical_freqs(a)
+    assert (f < 0.0011).sum() == 8 and abs(f.sum() - 1) < 1e-12
+    ref, refs = e.site_lnl(po.Tree(nw, a))
+    r = gpu_ctx.score([(names, rows)], [nw], alpha=0.9, pi_mode=engine.PI_EMPIRICAL, site_lnl=True)[0]
+    assert abs(r["lnl"] - ref) < 1e-9 * abs(ref) and np.abs(r["site_lnl"] - refs).max() < 1e-9
+
+
 def test_wagf_search_vs_oracle(gpu_ctx, oracle_lib):
     po = oracle_lib
     names, rows, nw = synth.simulate_alignment(14, 500, 8950, 0.8)
