@@ -943,10 +943,15 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
                 d.out = stab; d.out_scl = sscl;
                 NewtonReq &nr = hnewt[in];
                 nr.md = model_of((int)g); nr.tag_base = tag_base; nr.pad0 = 0;
-                if (fuse_ok && tails_of[g].size() == 1 && t.after < 0 && !t.patlnl_dev && newton_reg_form(mp)) {
+                // (any number of tails per gene, anywhere in its list: every request has its own exchange block, the gene's workgroups
+                // walk the list in step.  An NNI round -- three tails per internal edge -- then neither writes nor re-reads its pooled
+                // sumtables, 640 B per pattern and tail.  PML_FUSE_MULTI=0: only a gene's single, last tail, the A-B arm)
+                static const bool fuse_multi = !(std::getenv("PML_FUSE_MULTI") && std::atoi(std::getenv("PML_FUSE_MULTI")) == 0);
+                if (fuse_ok && (fuse_multi || (tails_of[g].size() == 1 && t.after < 0)) && !t.patlnl_dev && newton_reg_form(mp)) {
                     d.flags |= OPF_FUSED_NEWTON; d.aux = (const NewtonReq *)(ds + o_newt) + in;
                     fused_req[in] = 1; any_fused = true; any_chain = true;
                 }
+                last_nv = -1; last_nv_op = -1;              // a sumtable operation leaves ITS tile in the wave's registers (kernels.hip chunk_op): the chain ends here
                 tail_req[&t - tails.data()] = (int)in;
                 nr.ticket0 = 0; nr.pad = 0;
                 nr.sumtab = stab; nr.weight = G.d_weight; nr.scl = sscl;
@@ -1116,8 +1121,10 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         for (auto &t : tails) {
             if (t.mode == MODE_EVALUATE_CAT) continue;
             const double *h = result_of(t);
+#ifndef ABL_KEEP_GOING      // timing-only ablation builds (tools/ab_w1_ablation.sh) compute garbage on purpose
             if (h && !std::isfinite(t.mode == MODE_EVALUATE ? h[0] : h[1]))
                 return ctx->fail(-5, t.mode == MODE_EVALUATE ? "device returned a non-finite likelihood" : "k_newton: non-finite branch likelihood (also from the no-exchange form)");
+#endif
         }
     }
     for (auto &o : ops) if (o.out_kind == SIDE_MSG) { Gene &G = genes[o.gene]; G.valid[o.out_id] = o.unstored ? 0 : 1; G.pend_level[o.out_id] = -1; }
@@ -1186,7 +1193,9 @@ int Batch::replay_plan(double *lnl) {
     }
     for (auto &o : P.outs) genes[o.first].valid[o.second] = 1;
     for (size_t g = 0; g < genes.size(); ++g) lnl[g] = res((int)g)[0];
+#ifndef ABL_KEEP_GOING
     if (!chain) for (size_t g = 0; g < genes.size(); ++g) if (!std::isfinite(lnl[g])) return ctx->fail(-5, "device returned a non-finite likelihood");
+#endif
     for (size_t g = 0; g < genes.size(); ++g) det_record(det_id, genes[g], 'R', 0, 0, lnl[g], genes[g].alpha, 0);
     return 0;
 }

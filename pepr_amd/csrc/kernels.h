@@ -63,6 +63,8 @@ constexpr int OPF_NT_STORE = 16;
 // newview is still in its registers when the next operation of the gene consumes it (post-order: a parent directly follows
 // its last-computed child).  OPF_CHAIN_L / OPF_CHAIN_R: that side (kind SK_CLV) is taken from the registers instead of being
 // read back; OPF_NO_STORE: the result is consumed that way only and is not written at all (whole-tree scoring).
+// OPF_CHAIN_R is honoured on MODE_EVALUATE* operations only (a newview's chained child always goes left, engine.cpp); a
+// MODE_SUMTABLE operation leaves its own tile in those registers, so nothing is chained from across one.
 constexpr int OPF_CHAIN_L = 32, OPF_CHAIN_R = 64, OPF_NO_STORE = 128;
 // Fused branch Newton (k_oplist<11>, round 3): a MODE_SUMTABLE operation that is the LAST operation of its gene in the launch
 // does not store its table -- a workgroup's tile of it (128 patterns x 80 rows) stays in the 80 VGPRs per wave that register

@@ -36,6 +36,9 @@ namespace pml {
 #define LOG_2_256 177.445678223345993274051579105116
 
 __device__ __forceinline__ double mfma4(double a, double b, double c) {
+#ifdef ABL_NO_MFMA
+    return __builtin_fma(a, b, c);       // timing-only ablation: the dependency without the matrix pipe
+#endif
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
@@ -368,7 +371,10 @@ __device__ __forceinline__ void contract(double (&acc)[5][2], const double *__re
     // say the LDS reads cost 20 % -- but two steps ahead (10 more VGPRs, 3 spills) measures 0.677 vs 0.673: it is not the
     // latency of one read that is exposed
 #ifdef ABL_NO_LDS
-#define FRAG_RD(x) (0.05)
+// a DIFFERENT constant per fragment element: with one constant for all of them the five state-tile chains of a contraction are
+// identical and the compiler merges them -- four fifths of the MFMAs disappear (the "LDS reads cost 20 %" of the first
+// ablation was that, not the reads)
+#define FRAG_RD(x) (0.05 + 1.0e-4 * (double)(&(x) - frag_c))
 #else
 #define FRAG_RD(x) (x)
 #endif
@@ -397,9 +403,13 @@ __device__ __forceinline__ void contract(double (&acc)[5][2], const double *__re
 // st-outer form for the SECOND side: produces one state tile (2 values) at a time so the caller can
 // consume it immediately (multiply with the first side's tile and store): 4 live accumulator
 // registers instead of 40.  Fragments of the next tiles are fetched while the current one runs.
+#ifndef PML_CONSUME_LATE
+#define PML_CONSUME_LATE 0
+#endif
 template <typename F>
 __device__ __forceinline__ void contract_stream(const double *__restrict__ frag_c, const Operand &o, F &&consume) {
     double a[3][5];
+    double p0 = 0.0, p1 = 0.0;
 #pragma unroll
     for (int kk = 0; kk < 5; ++kk) a[0][kk] = FRAG_RD(frag_c[kk * 16]);
     if (PML_FRAG_AHEAD >= 2) {
@@ -417,10 +427,22 @@ __device__ __forceinline__ void contract_stream(const double *__restrict__ frag_
         for (int kk = 0; kk < 5; ++kk) {
             acc0 = mfma4(a[st % 3][kk], o.v[kk].x, acc0);
             acc1 = mfma4(a[st % 3][kk], o.v[kk].y, acc1);
+#if PML_CONSUME_LATE
+            // the previous state tile is consumed (multiply, maximum, store) in the shadow of this tile's MFMAs instead of
+            // behind its own, where the wave would wait for the matrix pipe to drain and then issue VALU work with the pipe idle
+            if (kk == 0 && st > 0) consume(st - 1, p0, p1);
+#endif
         }
+#if PML_CONSUME_LATE
+        p0 = acc0; p1 = acc1;
+#else
         consume(st, acc0, acc1);
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
+#if PML_CONSUME_LATE
+    consume(4, p0, p1);
+#endif
 }
 
 // cherry operand: product of the two tips' table rows (tables live in global memory, L2-resident:
@@ -447,6 +469,20 @@ __device__ __forceinline__ void load_cherry(Operand &o, const OpSide &sd, unsign
     o.v[2] = (dvec2){a0.b.x * b0.b.x, a1.b.x * b1.b.x};
     o.v[3] = (dvec2){a0.b.y * b0.b.y, a1.b.y * b1.b.y};
     o.v[4] = (dvec2){a0.c * b0.c, a1.c * b1.c};
+}
+// the same in two halves, so that the rows of the NEXT category can be in flight during the current category's second contraction
+// (40 VGPRs of raw rows: affordable since the result tile is written straight into X, round 3)
+struct CherryRaw { Rows5 a0, a1, b0, b1; };
+__device__ __forceinline__ void issue_cherry(CherryRaw &r, const OpSide &sd, unsigned ca, unsigned cb, int c, int q) {
+    r.a0 = load_rows(sd.t0, ca & 0xFFu, c, q); r.a1 = load_rows(sd.t0, ca >> 8, c, q);
+    r.b0 = load_rows(sd.t1, cb & 0xFFu, c, q); r.b1 = load_rows(sd.t1, cb >> 8, c, q);
+}
+__device__ __forceinline__ void finish_cherry(Operand &o, const CherryRaw &r) {
+    o.v[0] = (dvec2){r.a0.a.x * r.b0.a.x, r.a1.a.x * r.b1.a.x};
+    o.v[1] = (dvec2){r.a0.a.y * r.b0.a.y, r.a1.a.y * r.b1.a.y};
+    o.v[2] = (dvec2){r.a0.b.x * r.b0.b.x, r.a1.b.x * r.b1.b.x};
+    o.v[3] = (dvec2){r.a0.b.y * r.b0.b.y, r.a1.b.y * r.b1.b.y};
+    o.v[4] = (dvec2){r.a0.c * r.b0.c, r.a1.c * r.b1.c};
 }
 // pitchfork operand for category c: ((F_inner . (T_a * T_b)) * T_c), all in registers
 __device__ __forceinline__ void load_pitch(Operand &o, const OpSide &sd, const double *__restrict__ f_inner,
@@ -518,18 +554,31 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
     // lane's A-fragment element: 4*k + i with k = q, i = lane&3
     const double *fL = sP + (q * 4 + (lane & 3));
     const double *fR = fL + PFRAG;
-    double mx0 = 0.0, mx1 = 0.0, site0 = 0.0, site1 = 0.0;
+    // running maxima of the result entries of the lane's two patterns, kept as the HIGH WORDS of the doubles: the entries are
+    // non-negative, so their order is the order of their bit patterns, and x < 2^-256 <=> hi(x) < hi(2^-256) because the low word
+    // of 2^-256 is zero -- one integer max per entry instead of a double-precision one (a wave issues one of those per 12 cycles)
+    unsigned mx0 = 0u, mx1 = 0u;
+    double site0 = 0.0, site1 = 0.0;
     unsigned cl = 0, cl2 = 0, cl3 = 0, cr = 0, cr2 = 0, cr3 = 0;      // tip codes of the lane's two patterns
     // inner fragments of a pitchfork side: ONE extra LDS region, owned by the left side if it is a
     // pitchfork, else by the right; if both are, the right side reads its set from global memory (rare)
     const double *fLi = fL + 2 * PFRAG;
-    const double *fRi = (lk == SK_PITCH) ? sdr.f + (q * 4 + (lane & 3)) : fL + 2 * PFRAG;
-    if (lk != SK_CLV) cl = *reinterpret_cast<const GLOBAL_AS unsigned short *>(Lp + p);
-    if (lk >= SK_CHERRY) cl2 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)sdl.p1 + p);
-    if (lk == SK_PITCH) cl3 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)sdl.p2 + p);
-    if (rk != SK_CLV) cr = *reinterpret_cast<const GLOBAL_AS unsigned short *>(Rp + p);
-    if (rk >= SK_CHERRY) cr2 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)sdr.p1 + p);
-    if (rk == SK_PITCH) cr3 = *reinterpret_cast<const GLOBAL_AS unsigned short *>((gcptr)sdr.p2 + p);
+    // (two code paths, not one pointer chosen at run time: a pointer that may be global OR shared is a generic one, and every
+    // fragment read through it a FLAT load, which counts on both vmcnt and lgkmcnt -- each k-step of the inner contraction then
+    // waited for everything in flight: a right-hand pitchfork cost 11 k cycles more than a right-hand cherry for 100 more MFMAs)
+    const bool both_pitch = lk == SK_PITCH && rk == SK_PITCH;
+    const double *fRg = sdr.f + (q * 4 + (lane & 3));
+#ifdef ABL_NO_CODES      // timing-only ablation: tip codes made up from the pattern index instead of loaded
+#define CODE_LD(ptr) ((((unsigned)p * 5u + 1u + (unsigned)(size_t)(ptr)) % 20u) | ((((unsigned)p * 3u + 2u) % 20u) << 8))
+#else
+#define CODE_LD(ptr) (*reinterpret_cast<const GLOBAL_AS unsigned short *>(ptr))
+#endif
+    if (lk != SK_CLV) cl = CODE_LD(Lp + p);
+    if (lk >= SK_CHERRY) cl2 = CODE_LD((gcptr)sdl.p1 + p);
+    if (lk == SK_PITCH) cl3 = CODE_LD((gcptr)sdl.p2 + p);
+    if (rk != SK_CLV) cr = CODE_LD(Rp + p);
+    if (rk >= SK_CHERRY) cr2 = CODE_LD((gcptr)sdr.p1 + p);
+    if (rk == SK_PITCH) cr3 = CODE_LD((gcptr)sdr.p2 + p);
 
     // A tip side with plain amino-acid codes needs no contraction: (P e_a)[s] = P[s][a] is an element of the fragment set
     // already in LDS (A-fragment order: P[4 st + i][4 kk + k] at (st*5 + kk)*16 + k*4 + i) -- 5 LDS reads per pattern and
@@ -540,6 +589,7 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
     const double *tL0 = sP + ((cl & 0xFFu) >> 2) * 16 + (cl & 3u) * 4 + q, *tL1 = sP + ((cl >> 8) >> 2) * 16 + ((cl >> 8) & 3u) * 4 + q;
     const double *tR0 = sP + PFRAG + ((cr & 0xFFu) >> 2) * 16 + (cr & 3u) * 4 + q, *tR1 = sP + PFRAG + ((cr >> 8) >> 2) * 16 + ((cr >> 8) & 3u) * 4 + q;
     Operand curL, curR, nxtL, nxtR;
+    CherryRaw rawR;
     if (lk == SK_TIP && !lookL) load_tip(curL, sT, cl, q);
     else if (lk == SK_CLV && !chL) load_clv(curL, Lp, lane_off, rowbytes, 0);      // evaluate: left side in output layout
     if (rk == SK_TIP && !lookR) load_tip(curR, sT, cr, q);
@@ -548,7 +598,15 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
 #pragma unroll CAT_UNROLL
     for (int c = 0; c < NCAT; ++c) {
         Operand Y;                                            // CHAIN: this category of the result
-        if (CHAIN) {
+        // (fully unrolled: a chained side is contracted straight out of X[c] -- its own code path below -- instead of being copied
+        // into the operand registers first: 10 v_mov_b64 per category and side, at the 12 cycles a wave pays per double-precision
+        // VALU instruction, tools/ubench_f64.hip)
+        constexpr bool DIRECT = CHAIN && CAT_UNROLL == NCAT;        // results are written straight into X[c]
+#ifndef PML_DIRECT_FUSE
+#define PML_DIRECT_FUSE 0
+#endif
+        constexpr bool DIRECT_IN = DIRECT && (!FUSE || PML_DIRECT_FUSE);    // chained operands are read straight from X[c]
+        if (CHAIN && !DIRECT_IN) {
             if (CAT_UNROLL == NCAT) { if (chL) curL = X[c]; if (chR) curR = X[c]; }
             else { if (chL) curL = X[0]; if (chR) curR = X[0]; }     // X is rotated once per category: X[0] is category c
         }
@@ -556,12 +614,31 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
             if (PF_L && lk == SK_CLV && !chL) load_clv(nxtL, Lp, lane_off, rowbytes, c + 1);
             if (rk == SK_CLV && !chR) load_clv(nxtR, Rp, lane_off, rowbytes, c + 1);
         }
+        // PML_PF_ROWS (A-B arms, both measured slower, profiles/r03_kernel_steps.txt): 1 = a right-hand cherry's rows requested one
+        // category ahead (40 VGPRs of raw rows live through the second contraction: 123 spills), 2 = requested in front of the
+        // left contraction of the same category and multiplied behind it (63 spills, 0.60 -> 0.72 ms)
+#ifndef PML_PF_ROWS
+#define PML_PF_ROWS 0
+#endif
+        constexpr bool PF_ROWS = PML_PF_ROWS && DIRECT && !FUSE;
+        const bool pfR = PF_ROWS && rk == SK_CHERRY && lk == SK_CLV && mode < MODE_EVALUATE;     // right-hand cherry next to a CLV: rows requested early
+        // (first thing in the category: the 40 raw-row registers die here, before the left side builds its own operand)
+#if PML_PF_ROWS == 1
+        if (pfR) { if (c == 0) issue_cherry(rawR, sdr, cr, cr2, 0, q); finish_cherry(curR, rawR); }
+#else
+        // PML_PF_ROWS == 2: the rows of THIS category are requested here and multiplied behind the left contraction, whose 50 MFMAs
+        // cover most of their L2 round trip; nothing stays live across categories
+        if (pfR) issue_cherry(rawR, sdr, cr, cr2, c, q);
+#endif
         if (lk == SK_CHERRY) load_cherry(curL, sdl, cl, cl2, c, q);
         else if (lk == SK_PITCH) load_pitch(curL, sdl, fLi, cl, cl2, cl3, c, q);
-        if (rk == SK_CHERRY) load_cherry(curR, sdr, cr, cr2, c, q);
-        else if (rk == SK_PITCH) load_pitch(curR, sdr, fRi, cr, cr2, cr3, c, q);
+        if (pfR) {}
+        else if (rk == SK_CHERRY) load_cherry(curR, sdr, cr, cr2, c, q);
+        else if (rk == SK_PITCH) { if (both_pitch) load_pitch(curR, sdr, fRg, cr, cr2, cr3, c, q); else load_pitch(curR, sdr, fLi, cr, cr2, cr3, c, q); }
         if (mode >= MODE_EVALUATE) {
-            contract_stream(fR + c * 25 * 16, curR, [&](int st, double y0, double y1) {
+            if (DIRECT_IN && chL) contract_stream(fR + c * 25 * 16, curR, [&](int st, double y0, double y1) { site0 += X[c].v[st].x * y0; site1 += X[c].v[st].y * y1; });
+            else if (DIRECT_IN && chR) contract_stream(fR + c * 25 * 16, X[c], [&](int st, double y0, double y1) { site0 += curL.v[st].x * y0; site1 += curL.v[st].y * y1; });
+            else contract_stream(fR + c * 25 * 16, curR, [&](int st, double y0, double y1) {
                 site0 += curL.v[st].x * y0; site1 += curL.v[st].y * y1;
             });
             if (mode == MODE_EVALUATE_CAT) {          // this category's likelihood goes out on its own (row c of the table slice)
@@ -576,12 +653,24 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
             if (lookL) {
 #pragma unroll
                 for (int st = 0; st < 5; ++st) { aL[st][0] = tL0[c * 400 + st * 80]; aL[st][1] = tL1[c * 400 + st * 80]; }
-            } else contract(aL, fL + c * 25 * 16, curL);
+            } else if (DIRECT_IN && chL) contract(aL, fL + c * 25 * 16, X[c]);
+            else contract(aL, fL + c * 25 * 16, curL);
+#if PML_PF_ROWS == 1
+            if (pfR && c + 1 < NCAT) issue_cherry(rawR, sdr, cr, cr2, c + 1, q);
+#else
+            if (pfR) finish_cherry(curR, rawR);
+#endif
             auto emit = [&](int st, double y0, double y1) {
                 const double o0 = aL[st][0] * y0, o1 = aL[st][1] * y1;
-                mx0 = fmax(mx0, o0); mx1 = fmax(mx1, o1);
-                if (CHAIN) Y.v[st] = (dvec2){o0, o1};
+                mx0 = max(mx0, (unsigned)__double2hiint(o0)); mx1 = max(mx1, (unsigned)__double2hiint(o1));
+                // fully unrolled: the result tile goes straight into X[c] (the left contraction of this category, the only reader
+                // of the old X[c], is complete) -- for sumtable operations too, which therefore END a chain (engine.cpp: nothing is
+                // chained from across a sumtable tail)
+                if (CHAIN) { if (DIRECT) X[c].v[st] = (dvec2){o0, o1}; else Y.v[st] = (dvec2){o0, o1}; }
                 if (!keep) return;
+#ifdef ABL_NO_STORE
+                return;
+#endif
                 // buffer stores: the cache policy is an immediate of the instruction, so the two policies are two instructions
                 // under a wave-uniform branch (an if/else of a plain and a __builtin_nontemporal_store is merged by hipcc
                 // into ONE plain store)
@@ -595,9 +684,8 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
                 for (int st = 0; st < 5; ++st) emit(st, tR0[c * 400 + st * 80], tR1[c * 400 + st * 80]);
             } else contract_stream(fR + c * 25 * 16, curR, emit);
         }
-        if (CHAIN) {
-            if (CAT_UNROLL == NCAT) { if (mode == MODE_NEWVIEW || fusedN) X[c] = Y; }
-            else if (mode == MODE_NEWVIEW) { X[0] = X[1]; X[1] = X[2]; X[2] = X[3]; X[3] = Y; }
+        if (CHAIN && !DIRECT) {
+            if (mode == MODE_NEWVIEW) { X[0] = X[1]; X[1] = X[2]; X[2] = X[3]; X[3] = Y; }
             else if (chL || chR) { const Operand t = X[0]; X[0] = X[1]; X[1] = X[2]; X[2] = X[3]; X[3] = t; }   // a tail leaves X as it was
         }
         if (c + 1 < NCAT) {
@@ -615,9 +703,10 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
         if (rk == SK_CLV) { if (chR) sc += xsc; else sc += *reinterpret_cast<const GLOBAL_AS ivec2 *>((gcptr)r_scl + 4 * p); }
     }
     if (mode == MODE_NEWVIEW) {
-        mx0 = fmax(mx0, __shfl_xor(mx0, 16)); mx0 = fmax(mx0, __shfl_xor(mx0, 32));
-        mx1 = fmax(mx1, __shfl_xor(mx1, 16)); mx1 = fmax(mx1, __shfl_xor(mx1, 32));
-        const bool n0 = mx0 < TWO_M256, n1 = mx1 < TWO_M256;
+        mx0 = max(mx0, (unsigned)__shfl_xor((int)mx0, 16)); mx0 = max(mx0, (unsigned)__shfl_xor((int)mx0, 32));
+        mx1 = max(mx1, (unsigned)__shfl_xor((int)mx1, 16)); mx1 = max(mx1, (unsigned)__shfl_xor((int)mx1, 32));
+        constexpr unsigned HI_TWO_M256 = (1023u - 256u) << 20;
+        const bool n0 = mx0 < HI_TWO_M256, n1 = mx1 < HI_TWO_M256;
         if (__any(n0 || n1)) {               // rare: numerical rescue of underflowing patterns
             if (CHAIN) {
                 const double f0 = n0 ? TWO_P256 : 1.0, f1 = n1 ? TWO_P256 : 1.0;
@@ -769,6 +858,16 @@ __device__ __forceinline__ void newton_fused(const NvOp &op, double *scratch, co
     }
 }
 
+#ifdef PML_OPTIME
+__device__ unsigned long long g_optime[256][2];
+} // namespace pml
+extern "C" void pml_abl_optime(unsigned long long *out, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pml::g_optime), sizeof(unsigned long long) * 512);
+    if (reset) { static unsigned long long z[512]; (void)hipMemcpyToSymbol(HIP_SYMBOL(pml::g_optime), z, sizeof z); }
+}
+namespace pml {
+#endif
 template <int VARIANT>
 // VARIANT 5 = variant 1 compiled for 3 waves/SIMD (168 VGPRs, no spills)
 // VARIANT 9 = variant 1 with register chaining (kernels.h OPF_CHAIN_*): 80 more live VGPRs, 2 waves/SIMD
@@ -867,7 +966,18 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : (VARIANT >= 8) ? PML_CHAI
             }
             __syncthreads();
         }
+#ifdef PML_OPTIME         // diagnostic build (tools/optime.sh): shader-clock cycles per operation, by the kinds of its sides
+        const long long t_op0 = clock64();
+#endif
+#ifndef ABL_NO_OP        // timing-only ablation: the shell alone (descriptor reads, fragment staging, barriers)
         if (active) chunk_op<PREFETCH, CHAIN, FUSE>(op, buf, sT, p, lane, X, xsc);
+#endif
+#ifdef PML_OPTIME
+        if (lane == 0 && active) {
+            const int k = (op.flags & 15) | ((op.mode & 3) << 4) | ((op.flags & (OPF_CHAIN_L | OPF_CHAIN_R)) ? 64 : 0) | ((op.flags & OPF_NO_STORE) ? 128 : 0);
+            atomicAdd(&g_optime[k][0], (unsigned long long)(clock64() - t_op0)); atomicAdd(&g_optime[k][1], 1ull);
+        }
+#endif
         if (FUSE && (op.flags & OPF_FUSED_NEWTON) != 0) {
             // a launch-wide abort (an exchange of this stream gave up earlier) is honoured before waiting on anybody
             if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
@@ -1597,7 +1707,7 @@ static void launch_oplist_one(const NvOp *ops, const GeneRun *runs, int nruns, i
     if (any_pitch && (v == 2 || v == 3)) v = 1;          // pitchfork regions are not combined with double buffering
     if (chained) {                                       // the descriptors carry OPF_CHAIN_* flags: only these variants honour them
         static const int cv = std::getenv("PML_CHAIN_VARIANT") ? std::atoi(std::getenv("PML_CHAIN_VARIANT")) : 11;
-        v = cv == 9 ? 9 : (cv == 16 ? 16 : 11);
+        v = cv == 9 ? 9 : (cv == 16 ? 16 : (cv == 10 ? 10 : 11));
         if (ctl) v = 15;
     }
     if (v == 16) {                                       // one pattern per lane, 8 waves per tile (k_oplist16)
@@ -1611,11 +1721,12 @@ static void launch_oplist_one(const NvOp *ops, const GeneRun *runs, int nruns, i
     }
     const bool dbuf = (v == 2 || v == 3);
     size_t lds = (size_t)((dbuf ? 4 : 2) + (any_pitch ? 1 : 0)) * PFRAG * sizeof(double) + 512;   // 38.9 KB with pitchforks: 4 per CU
-    if (v == 11 || v == 15) {
+    if (v == 11 || v == 15 || v == 10) {
         lds = (size_t)6 * PFRAG * sizeof(double) + 512;      // 77.3 KB: two workgroups per CU, which is what its 256 VGPRs allow anyway
         static const hipError_t big11 = [&] {
             const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void *>(k_oplist<11>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void *>(k_oplist<15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_oplist<10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             return a != hipSuccess ? a : b;
         }();
         if (big11 != hipSuccess && v == 11) {                // no 77 KB of dynamic LDS: the single-buffered chained variant (25.6-38.4 KB) does the same work
@@ -1629,6 +1740,7 @@ static void launch_oplist_one(const NvOp *ops, const GeneRun *runs, int nruns, i
         case 3: hipLaunchKernelGGL(k_oplist<3>, grid, block, lds, s, ops, runs, nruns, bpg, ap, ctl, to); break;
         case 5: hipLaunchKernelGGL(k_oplist<5>, grid, block, lds, s, ops, runs, nruns, bpg, ap, ctl, to); break;
         case 9: hipLaunchKernelGGL(k_oplist<9>, grid, block, lds, s, ops, runs, nruns, bpg, ap, ctl, to); break;
+        case 10: hipLaunchKernelGGL(k_oplist<10>, grid, block, lds, s, ops, runs, nruns, bpg, ap, ctl, to); break;
         case 11: hipLaunchKernelGGL(k_oplist<11>, grid, block, lds, s, ops, runs, nruns, bpg, ap, ctl, to); break;
         case 15: hipLaunchKernelGGL(k_oplist<15>, grid, block, lds, s, ops, runs, nruns, bpg, ap, ctl, to); break;
         default: hipLaunchKernelGGL(k_oplist<1>, grid, block, lds, s, ops, runs, nruns, bpg, ap, ctl, to); break;
