@@ -485,13 +485,19 @@ __device__ __forceinline__ void finish_cherry(Operand &o, const CherryRaw &r) {
     o.v[4] = (dvec2){r.a0.c * r.b0.c, r.a1.c * r.b1.c};
 }
 // pitchfork operand for category c: ((F_inner . (T_a * T_b)) * T_c), all in registers
+template <bool EARLY = true>
 __device__ __forceinline__ void load_pitch(Operand &o, const OpSide &sd, const double *__restrict__ f_inner,
                                            unsigned ca, unsigned cb, unsigned cc, int c, int q) {
     Operand w;
     load_cherry(w, sd, ca, cb, c, q);
+    // EARLY: the third tip's rows are requested BEFORE the inner contraction (whose scheduling fences keep everything behind it
+    // where the source puts it): behind it, as first written, their L2 round trip was waited for in full, once per category
+    // (C3 launch 0.570 -> 0.563 ms).  Not in the fused-Newton variant: 20 more live VGPRs there are 20 more spills (29 -> 49).
+    Rows5 r0, r1;
+    if (EARLY) { r0 = load_rows(sd.t2, cc & 0xFFu, c, q); r1 = load_rows(sd.t2, cc >> 8, c, q); }
     double v[5][2];
     contract(v, f_inner + c * 25 * 16, w);
-    const Rows5 r0 = load_rows(sd.t2, cc & 0xFFu, c, q), r1 = load_rows(sd.t2, cc >> 8, c, q);
+    if (!EARLY) { r0 = load_rows(sd.t2, cc & 0xFFu, c, q); r1 = load_rows(sd.t2, cc >> 8, c, q); }
     o.v[0] = (dvec2){v[0][0] * r0.a.x, v[0][1] * r1.a.x};
     o.v[1] = (dvec2){v[1][0] * r0.a.y, v[1][1] * r1.a.y};
     o.v[2] = (dvec2){v[2][0] * r0.b.x, v[2][1] * r1.b.x};
@@ -631,10 +637,10 @@ __device__ __forceinline__ void chunk_op(const NvOp &op, const double *__restric
         if (pfR) issue_cherry(rawR, sdr, cr, cr2, c, q);
 #endif
         if (lk == SK_CHERRY) load_cherry(curL, sdl, cl, cl2, c, q);
-        else if (lk == SK_PITCH) load_pitch(curL, sdl, fLi, cl, cl2, cl3, c, q);
+        else if (lk == SK_PITCH) load_pitch<!FUSE>(curL, sdl, fLi, cl, cl2, cl3, c, q);
         if (pfR) {}
         else if (rk == SK_CHERRY) load_cherry(curR, sdr, cr, cr2, c, q);
-        else if (rk == SK_PITCH) { if (both_pitch) load_pitch(curR, sdr, fRg, cr, cr2, cr3, c, q); else load_pitch(curR, sdr, fLi, cr, cr2, cr3, c, q); }
+        else if (rk == SK_PITCH) { if (both_pitch) load_pitch<!FUSE>(curR, sdr, fRg, cr, cr2, cr3, c, q); else load_pitch<!FUSE>(curR, sdr, fLi, cr, cr2, cr3, c, q); }
         if (mode >= MODE_EVALUATE) {
             if (DIRECT_IN && chL) contract_stream(fR + c * 25 * 16, curR, [&](int st, double y0, double y1) { site0 += X[c].v[st].x * y0; site1 += X[c].v[st].y * y1; });
             else if (DIRECT_IN && chR) contract_stream(fR + c * 25 * 16, X[c], [&](int st, double y0, double y1) { site0 += curL.v[st].x * y0; site1 += curL.v[st].y * y1; });
@@ -762,16 +768,33 @@ __device__ __forceinline__ void stage_frags_dma(const NvOp &op, double *dst, int
 #ifndef PML_CHAIN_WAVES
 #define PML_CHAIN_WAVES 2
 #endif
-// left | right | inner (pitchfork) fragment sets of one op into the three consecutive LDS regions at dst
+// left | right | inner (pitchfork) fragment sets of one op into the three consecutive LDS regions at dst.
+// A set is 12.5 rows of 1 KiB (one LDS-DMA instruction of 16 B per lane each); a wave takes one chunk of each set -- rows 4k..4k+3
+// through the instruction's immediate offset (it advances the global AND the LDS address), or the half row 12 -- with k rotated from
+// set to set so that the waves issue 9 to 12 instructions each.  The descriptor's pointers are read once, every address is a
+// wave-uniform base + lane * 16: about three instructions per KiB.  (The first version walked `for (i = wave; i < 25; i += 4)` over
+// the left | right pair with a per-lane choice of the source: the compiler re-read the descriptor from memory and waited for it
+// INSIDE the loop and spent ~25 instructions per KiB -- seen in the ISA after the single-wave ablations had shown that the kernel
+// is bound by what a wave issues, not by memory: C3 launch 0.595 -> 0.572 ms.  Issuing the staging from inside the category loop
+// instead of in front of the operation, so that the operation's own first loads are not queued behind it, measured SLOWER: 0.580-0.586.)
+__device__ __forceinline__ void dma_chunk(const double *set, double *lds_set, int k, int lane) {
+    const GLOBAL_AS char *src = (const GLOBAL_AS char *)set + k * 4096 + lane * 16;
+    __attribute__((address_space(3))) char *dst = (__attribute__((address_space(3))) char *)lds_set + k * 4096;
+    if (k < 3) {
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)src, (__attribute__((address_space(3))) void *)dst, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)src, (__attribute__((address_space(3))) void *)dst, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)src, (__attribute__((address_space(3))) void *)dst, 16, 3072, 0);
+    } else if (lane < 32) __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+}
 __device__ __forceinline__ void stage_frags_dma3(const NvOp &op, double *dst, int lane, int wave) {
-    stage_frags_dma(op, dst, lane, wave);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const double *pl = op.pl, *pr = op.pr;
     const int lk = op.flags & 3, rk = (op.flags >> 2) & 3;
     const double *inner = (lk == SK_PITCH) ? op.l.f : (rk == SK_PITCH) ? op.r.f : nullptr;
-    if (inner == nullptr) return;
-    for (int i = wave; i < 13; i += 4) {          // PFRAG doubles = 12.5 wave-instructions of 1 KiB
-        const int e = i * 128 + lane * 2;
-        if (e < PFRAG) __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(inner + e), (__attribute__((address_space(3))) void *)(dst + 2 * PFRAG + i * 128), 16, 0, 0);
-    }
+    dma_chunk(pl ? pl : pr, dst, wv, lane);
+    dma_chunk(pr ? pr : pl, dst + PFRAG, (wv + 1) & 3, lane);
+    if (inner != nullptr) dma_chunk(inner, dst + 2 * PFRAG, (wv + 2) & 3, lane);
 }
 
 // Fused branch Newton (OPF_FUSED_NEWTON): the workgroups of one gene -- one 128-pattern tile of the sumtable each, in X --
