@@ -193,6 +193,9 @@ __global__ __launch_bounds__(256) void k_eigfrags(const ModelDev *__restrict__ m
 
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
+#ifdef PML_OPTIME       // diagnostic build: cycle counters (tools/optime.sh, tools/optime_search.py); see g_optime below
+extern __device__ unsigned long long g_optime[256][2];
+#endif
 __device__ __forceinline__ void st_granule(u64 *p, u64 v) {
     __hip_atomic_store((gu64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -246,6 +249,9 @@ __device__ __forceinline__ bool newton_exchange(u64 *gran, int S, int wg, int ne
         st_granule(slot + wg * 6 + lane, (want << 32) | ((lane & 1) ? (bits >> 32) : (bits & 0xFFFFFFFFull)));
     }
     u64 x[6] = {0, 0, 0, 0, 0, 0};
+#ifdef PML_OPTIME
+    const long long t_poll0 = clock64();
+#endif
     const long long t_start = wall_clock64();
     unsigned polls = 0;
     bool bad = false;
@@ -282,6 +288,9 @@ __device__ __forceinline__ bool newton_exchange(u64 *gran, int S, int wg, int ne
             }
         }
     }
+#ifdef PML_OPTIME        // [246] all gathers, [247] the first gather of a request
+    if (lane == 0) { atomicAdd(&g_optime[246][0], (unsigned long long)(clock64() - t_poll0)); atomicAdd(&g_optime[246][1], 1ull); if (nevals == 0) atomicAdd(&g_optime[247][0], (unsigned long long)(clock64() - t_poll0)); }
+#endif
 #pragma unroll
     for (int i = 0; i < 3; ++i) {   // lanes >= S contribute +0.0 (exact); fixed shuffle tree: a function of S alone
         const u64 bits = ((x[2 * i + 1] & 0xFFFFFFFFull) << 32) | (x[2 * i] & 0xFFFFFFFFull);
@@ -900,6 +909,9 @@ template <int VARIANT>
 __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : (VARIANT >= 8) ? PML_CHAIN_WAVES : 3) void k_oplist(
         const NvOp *__restrict__ ops, const GeneRun *__restrict__ runs, int nruns, int blocks_per_gene, int any_pitch,
         NewtonCtl *ctl, long long timeout_ticks) {
+#ifdef PML_OPTIME
+    const long long t_life0 = clock64();
+#endif
     constexpr bool PREFETCH = !(VARIANT & 1);
     constexpr bool CHAIN = VARIANT >= 8;                  // 8..11, 15: bit 0 / bit 1 as above, three LDS regions per parity
     constexpr bool FUSE = VARIANT == 15;
@@ -957,9 +969,16 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : (VARIANT >= 8) ? PML_CHAI
     const int p = (blk * 4 + wave) * PAT_PER_WAVE + 2 * (lane & 15);
     const bool active = (blk * 4 + wave) * PAT_PER_WAVE < mpad;
 
+#ifdef PML_OPTIME
+    const long long t_start1 = clock64();        // slot claimed, run descriptor read
+#endif
     for (int i = tid; i < TIPTAB; i += 256) sT[i] = (unsigned char)((code_mask(i / NS) >> (i % NS)) & 1u);
     if (DBUF) { if (DBUF3) stage_frags_dma3(ops[run.op_begin], sP, lane, wave); else stage_frags_dma(ops[run.op_begin], sP, lane, wave); }
     __syncthreads();
+#ifdef PML_OPTIME
+    const long long t_start2 = clock64();        // tip table filled, first fragment sets staged and landed
+    long long t_newton = 0, t_bar = 0, t_ops = 0;
+#endif
     for (int oi = run.op_begin; oi < run.op_end; ++oi) {
         const NvOp &op = ops[oi];
         const double *buf = sP;
@@ -1000,6 +1019,8 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : (VARIANT >= 8) ? PML_CHAI
             const int k = (op.flags & 15) | ((op.mode & 3) << 4) | ((op.flags & (OPF_CHAIN_L | OPF_CHAIN_R)) ? 64 : 0) | ((op.flags & OPF_NO_STORE) ? 128 : 0);
             atomicAdd(&g_optime[k][0], (unsigned long long)(clock64() - t_op0)); atomicAdd(&g_optime[k][1], 1ull);
         }
+        t_ops += clock64() - t_op0;
+        const long long t_n0 = clock64();
 #endif
         if (FUSE && (op.flags & OPF_FUSED_NEWTON) != 0) {
             // a launch-wide abort (an exchange of this stream gave up earlier) is honoured before waiting on anybody
@@ -1008,10 +1029,25 @@ __global__ __launch_bounds__(256, (VARIANT == 1) ? 4 : (VARIANT >= 8) ? PML_CHAI
                 if (tid == 0 && blk == 0) { r.out[0] = r.t0; r.out[1] = __builtin_nan(""); r.out[2] = 0.0; r.out[3] = 0.0; }
             } else newton_fused(op, const_cast<double *>(buf), X, xsc, active, blk, ctl, timeout_ticks);
         }
+#ifdef PML_OPTIME
+        const long long t_b0 = clock64(); t_newton += t_b0 - t_n0;
+#endif
 #ifndef ABL_NO_BARRIER
         if (DBUF) __syncthreads();           // next fragments landed (vmcnt(0) + barrier), stores done
 #endif
+#ifdef PML_OPTIME
+        t_bar += clock64() - t_b0;
+#endif
     }
+#ifdef PML_OPTIME
+    if (lane == 0 && active) {
+        const int b = FUSE ? 230 : 238;           // [b] lifetime, [b+1] claim + descriptor, [b+2] table + first staging, [b+3] operations, [b+4] Newton, [b+5] barrier
+        const long long t_end = clock64();
+        atomicAdd(&g_optime[b][0], (unsigned long long)(t_end - t_life0)); atomicAdd(&g_optime[b][1], 1ull);
+        atomicAdd(&g_optime[b + 1][0], (unsigned long long)(t_start1 - t_life0)); atomicAdd(&g_optime[b + 2][0], (unsigned long long)(t_start2 - t_start1));
+        atomicAdd(&g_optime[b + 3][0], (unsigned long long)t_ops); atomicAdd(&g_optime[b + 4][0], (unsigned long long)t_newton); atomicAdd(&g_optime[b + 5][0], (unsigned long long)t_bar);
+    }
+#endif
     leave();
 }
 

@@ -22,7 +22,7 @@ def mfmas(lk, rk, mode, chained):
     per = {0: 100, 1: 0, 2: 0, 3: 100}
     n = (per[lk] + (100 if lk in (2, 3) else 0)) + (per[rk] + (100 if rk in (2, 3) else 0))
     return n * 2
-life, bar = a[255].copy(), a[254].copy(); a[254:] = 0
+life, bar = a[238].copy(), a[243].copy(); a[230:] = 0
 tot = a[:, 0].sum()
 if life[1]: print("  wave lifetimes: %.0f waves/launch, %.0f cycles each; inside operations %.3f of it, waiting at the per-operation barrier (+ staged fragments) %.3f, rest (start-up, descriptors, staging) %.3f"
                   % (life[1] / N, life[0] / life[1], tot / life[0], bar[0] / life[0], 1 - (tot + bar[0]) / life[0]))
