@@ -692,7 +692,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     const double t_begin = now_ms();
     HIPCHK(hipSetDevice(ctx->device));
     // group by gene, keeping each gene's dependency order (children are emitted before parents)
-    std::stable_sort(ops.begin(), ops.end(), [](const PendingOp &a, const PendingOp &b) { return a.gene < b.gene; });
+    std::stable_sort(ops.begin(), ops.end(), [](const PendingOp &a, const PendingOp &b) { return a.gene != b.gene ? a.gene < b.gene : a.part < b.part; });
     const size_t nops = ops.size(), ntail = tails.size();
     size_t neval = 0, nnewton = 0;
     for (auto &t : tails) { if (t.mode == MODE_EVALUATE) neval++; else if (t.mode != MODE_EVALUATE_CAT) nnewton++; }
@@ -735,10 +735,17 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     double *const frags_buf = lane ? d_frags2 : d_frags;
     ctx->tic_stream = st;
     const size_t ngenes = genes.size();
+    // runs of the launch: one per (gene, part) -- parts of a gene are independent of each other (PendingOp::part)
+    std::vector<int> &nparts = run_nparts; nparts.assign(ngenes, 1);
+    for (auto &o : ops) nparts[o.gene] = std::max(nparts[o.gene], o.part + 1);
+    for (auto &t : tails) nparts[t.gene] = std::max(nparts[t.gene], t.part + 1);
+    std::vector<size_t> &koff = run_koff; koff.assign(ngenes + 1, 0);
+    for (size_t g = 0; g < ngenes; ++g) koff[g + 1] = koff[g] + (size_t)nparts[g];
+    const size_t nkeys = koff[ngenes];
     const size_t o_req = 0;
     const size_t o_ops = align_up(o_req + nreq_max * sizeof(PmatReq), 256);
     const size_t o_runs = align_up(o_ops + (nops + ntail) * sizeof(NvOp), 256);
-    const size_t o_red = align_up(o_runs + ngenes * sizeof(GeneRun), 256);
+    const size_t o_red = align_up(o_runs + nkeys * sizeof(GeneRun), 256);
     const size_t o_newt = align_up(o_red + neval * sizeof(ReduceReq), 256);
     size_t ntick_max = 0;                          // k_newton tickets: one per (request, slice)
     for (auto &t : tails) if (t.mode == MODE_SUMTABLE) ntick_max += (size_t)newton_split(genes[t.gene].aln.mpad);
@@ -768,8 +775,8 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
     if (fuse_ok && nnewton && !fuse_big_genes()) {
         int mm = 0; size_t nr = 0;
         std::vector<char> seen(genes.size(), 0);
-        for (auto &o : ops) if (!seen[o.gene]) { seen[o.gene] = 1; ++nr; mm = std::max(mm, genes[o.gene].aln.mpad); }
-        for (auto &t : tails) if (!seen[t.gene]) { seen[t.gene] = 1; ++nr; mm = std::max(mm, genes[t.gene].aln.mpad); }
+        for (auto &o : ops) if (!seen[o.gene]) { seen[o.gene] = 1; nr += (size_t)nparts[o.gene]; mm = std::max(mm, genes[o.gene].aln.mpad); }
+        for (auto &t : tails) if (!seen[t.gene]) { seen[t.gene] = 1; nr += (size_t)nparts[t.gene]; mm = std::max(mm, genes[t.gene].aln.mpad); }
         const size_t bpg = (size_t)(mm + TILE_PAT - 1) / TILE_PAT;
         if (bpg > 32 && nr * bpg > (size_t)fused_oplist_capacity()) fuse_ok = false;
     }
@@ -881,15 +888,16 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
 
     // tails by gene, in submission order (<= MAXTAIL per gene per run)
     std::vector<std::vector<int>> &tails_of = run_tails_of;          // kept between launches: no allocations per launch
-    if (tails_of.size() != ngenes) tails_of.assign(ngenes, {});
+    if (tails_of.size() < nkeys) tails_of.resize(nkeys);
     for (auto &v : tails_of) v.clear();
     for (size_t i = 0; i < ntail; ++i) {
         if (tails[i].slot < 0 || tails[i].slot >= MAXTAIL) return ctx->fail(-1, "internal: bad tail slot");
-        tails_of[tails[i].gene].push_back((int)i);
+        tails_of[koff[tails[i].gene] + (size_t)tails[i].part].push_back((int)i);
     }
-    for (size_t g = 0; g < ngenes; ++g) {
-        const bool has_ops = iop < nops && ops[iop].gene == (int)g;
-        if (!has_ops && tails_of[g].empty()) continue;
+    for (size_t g = 0; g < ngenes; ++g) for (int part = 0; part < nparts[g]; ++part) {
+        const size_t key = koff[g] + (size_t)part;
+        const bool has_ops = iop < nops && ops[iop].gene == (int)g && ops[iop].part == part;
+        if (!has_ops && tails_of[key].empty()) continue;
         Gene &G = genes[g];
         const int mp = G.aln.mpad;
         GeneRun &run = hruns[nruns++];
@@ -947,7 +955,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
                 // walk the list in step.  An NNI round -- three tails per internal edge -- then neither writes nor re-reads its pooled
                 // sumtables, 640 B per pattern and tail.  PML_FUSE_MULTI=0: only a gene's single, last tail, the A-B arm)
                 static const bool fuse_multi = !(std::getenv("PML_FUSE_MULTI") && std::atoi(std::getenv("PML_FUSE_MULTI")) == 0);
-                if (fuse_ok && (fuse_multi || (tails_of[g].size() == 1 && t.after < 0)) && !t.patlnl_dev && newton_reg_form(mp)) {
+                if (fuse_ok && (fuse_multi || (tails_of[key].size() == 1 && t.after < 0)) && !t.patlnl_dev && newton_reg_form(mp)) {
                     d.flags |= OPF_FUSED_NEWTON; d.aux = (const NewtonReq *)(ds + o_newt) + in;
                     fused_req[in] = 1; any_fused = true; any_chain = true;
                 }
@@ -967,8 +975,8 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
         };
         size_t ti = 0; int emitted = 0;
         auto flush_tails = [&](bool all) -> int {
-            while (ti < tails_of[g].size()) {
-                const Tail &t = tails[tails_of[g][ti]];
+            while (ti < tails_of[key].size()) {
+                const Tail &t = tails[tails_of[key][ti]];
                 if (!all && (t.after < 0 || t.after > emitted)) break;
                 if (int rc = emit_tail(t)) return rc;
                 ++ti;
@@ -976,7 +984,7 @@ int Batch::run(std::vector<PendingOp> &ops, const std::vector<Tail> &tails) {
             return 0;
         };
         if (int rc = flush_tails(false)) return rc;
-        for (; iop < nops && ops[iop].gene == (int)g; ++iop) {
+        for (; iop < nops && ops[iop].gene == (int)g && ops[iop].part == part; ++iop) {
             PendingOp &o = ops[iop];
             const int s = o.out_kind == SIDE_MSG ? slot_for(G, o.out_id) : G.slot_cap + o.out_id;
             if (s < 0) return ctx->fail(-4, "CLV slots exhausted (score-only batch used for a multi-root request)");

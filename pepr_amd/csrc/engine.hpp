@@ -92,7 +92,8 @@ struct GeneStore {
     void destroy();
 };
 
-constexpr int NSCRATCH = 8;          // extra CLV slots per gene for candidate evaluation (NNI / SPR)
+constexpr int NNI_PARTS = 6;         // parts an NNI round deals a gene's edges over (four scratch CLVs each)
+constexpr int NSCRATCH = 4 * NNI_PARTS > 8 ? 4 * NNI_PARTS : 8;   // extra CLV slots per gene for candidate evaluation (NNI: 4 per part; SPR: 8)
 enum { SIDE_TIP = 0, SIDE_MSG = 1, SIDE_SCRATCH = 2, SIDE_CHERRY = 3, SIDE_PITCH = 4 };
 // tip node id | directed-edge index (v-ntax)*3+k | scratch slot | directed-edge index of a message whose
 // two children are tips ("cherry": never materialised, recomputed from two tip tables where consumed)
@@ -101,7 +102,9 @@ struct Side { int kind, id; };
 // transition-matrix request among all operations of a launch that cross the same branch
 struct PendingOp { int gene, out_kind, out_id, level; Side child[2]; double t[2]; int bv[2] = {-1, -1}, bq[2] = {0, 0};
                    bool unstored = false; /* run(): the result stayed in registers (OPF_NO_STORE) and is not valid in memory */
-                   bool transient = false; /* caller: only the operation or tail that directly follows reads the result (scratch slots) */ };
+                   bool transient = false; /* caller: only the operation or tail that directly follows reads the result (scratch slots) */
+                   int part = 0; /* run(): operations and tails of one gene with different parts are independent of each other and become separate runs
+                                    of the launch (their workgroups run side by side): NNI rounds deal the edges of a gene over parts */ };
 
 struct Batch {
     Ctx *ctx = nullptr;
@@ -159,7 +162,7 @@ struct Batch {
     bool record_plan = false, record_stored = false;
     std::vector<ReqSrc> last_src;
     std::vector<size_t> req_off; std::vector<uint32_t> req_stamp; std::vector<const double *> req_ptr; uint32_t req_launch = 0;   // run(): keyed request table
-    std::vector<std::vector<int>> run_tails_of;
+    std::vector<std::vector<int>> run_tails_of; std::vector<int> run_nparts; std::vector<size_t> run_koff;
     std::vector<std::vector<std::pair<int, int>>> pass_order; std::vector<std::vector<uint8_t>> pass_next;      // smooth_pass scratch
     std::vector<std::vector<std::pair<uint64_t, const double *>>> val_bucket; std::vector<uint32_t> val_stamp;   // run(): requests shared by value
     // chained mode: run() enqueues its copy + kernels and returns WITHOUT synchronising; descriptors are bump-
@@ -229,7 +232,8 @@ struct Batch {
                   double *patlnl_dev = nullptr;               /* Newton tails: per-pattern lnL at the optimised length */
                   double *sumtab_dev = nullptr;               /* Newton tails: pooled sumtable (80*mpad doubles + mpad ints) instead of the gene's slot buffer */
                   int *scl_dev = nullptr;                     /* MODE_EVALUATE_CAT: where the scaling counts go (patlnl_dev = the 4 x mpad table slice) */
-                  const double *result_host = nullptr;        /* host view of result_dev when it is mapped memory (checked after the sync) */ };
+                  const double *result_host = nullptr;        /* host view of result_dev when it is mapped memory (checked after the sync) */
+                  int part = 0;                               /* as PendingOp::part */ };
     double *res(int g, int slot = 0) const { return h_scalars + 8 * ((size_t)g * MAXTAIL + slot); }
     Side msg(int g, int node, int toward) const;
     bool is_cherry(int g, int node, int toward) const;

@@ -197,14 +197,18 @@ int Batch::nni_round(const std::vector<char> &active, std::vector<double> &lnl, 
         if (int rc = ensure_tailpool(std::min(need_all, chunk * per_edge))) return rc;
         if (int rc = ensure_results(nres_all)) return rc;
     }
+    // The edges of a gene are dealt over NNI_PARTS parts (PendingOp::part): every part is a run of its own in the launch, with its
+    // own four scratch CLVs, so a gene's 3 x 47 Newton tails (C3) are worked on by several gangs of workgroups side by side instead
+    // of one after the other by one -- the round was latency-bound (21 ms for 128 C3 genes whose MFMA work is 3-4 ms).  The
+    // messages the edges read are brought up to date by a launch of their own first: parts must not depend on each other.
+    // PML_NNI_PARTS=1 is the A-B arm (one run per gene).
+    static const int parts_env = std::getenv("PML_NNI_PARTS") ? std::max(1, std::min(NNI_PARTS, std::atoi(std::getenv("PML_NNI_PARTS")))) : NNI_PARTS;
     for (size_t e0 = 0; e0 < nedge_max; e0 += chunk) {
         ++cnt_nni;
         std::vector<PendingOp> ops; std::vector<Tail> tails;
-        std::vector<int> nneed(n, 0);
         for (int g = 0; g < n; ++g) {              // every cached message the chunk's edges read
             if (!active[g]) continue;
             const Tree &T = genes[g].tree;
-            const size_t before = ops.size();
             for (size_t e = e0; e < std::min(edges[g].size(), e0 + chunk); ++e) {
                 auto [u, v] = edges[g][e];
                 int a[2], c[2]; double la[2], lc[2];
@@ -212,36 +216,42 @@ int Batch::nni_round(const std::vector<char> &active, std::vector<double> &lnl, 
                 need(g, u, v, ops); need(g, v, u, ops);
                 need(g, a[0], u, ops); need(g, a[1], u, ops); need(g, c[0], v, ops); need(g, c[1], v, ops);
             }
-            nneed[g] = (int)(ops.size() - before);
+        }
+        if (!ops.empty()) {
+            std::vector<Tail> none;
+            if (int rc = run(ops, none)) return rc;
+            ops.clear();
         }
         size_t pool_off = 0, ri = 0;
         std::vector<size_t> rbase(n, 0);
         for (int g = 0; g < n; ++g) {
             if (!active[g] || e0 >= edges[g].size()) continue;
             const Tree &T = genes[g].tree;
-            int count = nneed[g];
+            int count[NNI_PARTS] = {0};          // operations emitted so far, per part
             rbase[g] = ri;
             for (size_t e = e0; e < std::min(edges[g].size(), e0 + chunk); ++e) {
                 auto [u, v] = edges[g][e];
+                const int part = (int)((e - e0) % (size_t)parts_env), sbase = 4 * part;
                 const double t0 = T.len[u][T.slot(u, v)];
                 int a[2], c[2]; double la[2], lc[2];
                 others(T, u, v, a, la); others(T, v, u, c, lc);
                 auto pooled = [&](Tail t) {
                     t.sumtab_dev = reinterpret_cast<double *>(d_tailpool + pool_off); pool_off += tb[g];
                     t.result_dev = d_chain + 4 * ri; t.result_host = h_chain + 4 * ri; ++ri;
+                    t.part = part;
                     tails.push_back(t);
                 };
-                pooled({g, msg(g, u, v), msg(g, v, u), MODE_SUMTABLE, t0, 32, 0, nneed[g]});
+                pooled({g, msg(g, u, v), msg(g, v, u), MODE_SUMTABLE, t0, 32, 0, count[part]});
                 for (int alt = 1; alt <= 2; ++alt) {
-                    const int y = (alt == 1) ? 0 : 1, sx = 2 * alt - 2, sy = 2 * alt - 1;
-                    PendingOp X; X.gene = g; X.out_kind = SIDE_SCRATCH; X.out_id = sx; X.level = 0;
+                    const int y = (alt == 1) ? 0 : 1, sx = sbase + 2 * alt - 2, sy = sbase + 2 * alt - 1;
+                    PendingOp X; X.gene = g; X.part = part; X.out_kind = SIDE_SCRATCH; X.out_id = sx; X.level = 0;
                     X.child[0] = msg(g, a[0], u); X.t[0] = la[0]; X.bv[0] = u; X.bq[0] = T.slot(u, a[0]);
                     X.child[1] = msg(g, c[y], v); X.t[1] = lc[y]; X.bv[1] = v; X.bq[1] = T.slot(v, c[y]);
-                    PendingOp Y; Y.gene = g; Y.out_kind = SIDE_SCRATCH; Y.out_id = sy; Y.level = 0;
+                    PendingOp Y; Y.gene = g; Y.part = part; Y.out_kind = SIDE_SCRATCH; Y.out_id = sy; Y.level = 0;
                     Y.child[0] = msg(g, a[1], u); Y.t[0] = la[1]; Y.bv[0] = u; Y.bq[0] = T.slot(u, a[1]);
                     Y.child[1] = msg(g, c[1 - y], v); Y.t[1] = lc[1 - y]; Y.bv[1] = v; Y.bq[1] = T.slot(v, c[1 - y]);
-                    ops.push_back(X); ops.push_back(Y); count += 2;
-                    pooled({g, {SIDE_SCRATCH, sx}, {SIDE_SCRATCH, sy}, MODE_SUMTABLE, t0, 32, 0, count});
+                    ops.push_back(X); ops.push_back(Y); count[part] += 2;
+                    pooled({g, {SIDE_SCRATCH, sx}, {SIDE_SCRATCH, sy}, MODE_SUMTABLE, t0, 32, 0, count[part]});
                 }
             }
         }
