@@ -67,6 +67,14 @@ def test_search_groups_return_the_bits_of_the_undivided_call():
     for key in ("nni", "spr"):
         assert forced[key] == one[key], key
     assert forced["fallbacks"]["giveups"] > 0
+    # an NNI round deals a gene's edges over independent runs of the launch (search.cpp, PendingOp::part): one run per gene, the
+    # A-B arm, evaluates the same requests on the same inputs -- the same bits
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), PML_NNI_PARTS="1", PML_GROUPS="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "groups_harness.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    unparted = json.loads(p.stdout)
+    for key in ("nni", "spr"):
+        assert unparted[key] == one[key], key
 
 
 def test_two_contexts_search_concurrently_in_one_process(gpu_ctx):
